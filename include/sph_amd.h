@@ -1,0 +1,163 @@
+/*
+ * sph_amd -- C ABI of the MI355X SPH particle-pair path.
+ *
+ * The reference (jammy4536/SPH) has no plugin or FFI seam: its hot path is three free
+ * functions over C++ types plus file-scope globals, called from main() only.  Each entry
+ * point below names the reference function or lines it stands in for.  All entry points
+ * return SPH_OK (0) or an SPH_E* code; none throws or exits.  A context is driven by one
+ * host thread at a time.
+ *
+ * Precision contract (reference struct Particle, WCXSPH3D.cpp:81-92): positions, velocities,
+ * XSPH velocities and accelerations are double; rho, p, Rrho and m are float, and every
+ * place where the reference rounds through float is rounded through float here.
+ */
+#ifndef SPH_AMD_H
+#define SPH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    SPH_OK = 0,
+    SPH_EINVAL = 1,   /* bad argument or parameter */
+    SPH_EDEVICE = 2,  /* a HIP call failed; see sph_last_error */
+    SPH_ENOMEM = 3,
+    SPH_ESTATE = 4,   /* call made in the wrong order (e.g. step before upload) */
+    SPH_ECOMM = 5     /* RCCL failure in a multi-GPU context */
+};
+
+/* Which reference program's pair physics. */
+enum {
+    SPH_VARIANT_WCSPH = 0,  /* WCSPH.cpp: one global mass, no XSPH, x advanced with v */
+    SPH_VARIANT_WCXSPH = 1  /* WCXSPH.cpp / WCXSPH3D.cpp: per-particle mass, XSPH */
+};
+
+/* `particles` (state n) or `particlesh` (state n+1) of the reference's main(). */
+enum { SPH_STATE_N = 0, SPH_STATE_NP1 = 1 };
+
+/* Constants of one run: the reference's compile-time block (WCXSPH3D.cpp:39-79,97,142-143;
+ * WCXSPH.cpp:36-74,92; WCSPH.cpp:42-78,96) passed by value.  The caller computes them in
+ * the reference's operation order (sph_case_params does). */
+typedef struct sph_params {
+    int32_t  dim;              /* 2 or 3 */
+    int32_t  variant;          /* SPH_VARIANT_* */
+    uint64_t npts;             /* all particles, wall particles first */
+    uint64_t bound_parts;      /* original indices below this are wall particles */
+    double   H, HSQ;           /* support radius and its square */
+    double   correc;           /* kernel normalisation: 7/(4 pi H^2) or 21/(16 pi H^3) */
+    double   search_radius_sq; /* the reference's `search_radius` (a squared length) */
+    double   B, gam, rho0, Cs; /* Tait equation of state */
+    double   alpha, eps;       /* artificial viscosity, XSPH factor */
+    double   g;                /* added to f[g_axis] (reference: -9.81) */
+    int32_t  g_axis;
+    int32_t  subits;           /* Newmark-beta sweeps per step (reference: 8) */
+    double   beta;             /* Newmark beta as the reference holds it: (double)0.25f */
+    double   mass;             /* the single mass of SPH_VARIANT_WCSPH */
+    double   dt0;              /* initial time step (reference: 0.0002) */
+    /* Implementation knobs; 0 selects the default. */
+    double   skin_frac;        /* neighbour-candidate skin as a fraction of the search radius */
+    int32_t  max_neighbours;   /* initial per-particle candidate capacity (grows on demand) */
+    int32_t  device;           /* HIP device ordinal; -1 = current device */
+} sph_params;
+
+/* Caller-owned host arrays in ORIGINAL particle order, one array per component
+ * (x[0] holds all x coordinates).  NULL entries are skipped.  Layout of the reference's
+ * struct Particle, turned into structure-of-arrays. */
+typedef struct sph_fields {
+    double* x[3];
+    double* v[3];
+    double* V[3];
+    double* f[3];
+    float*  rho;
+    float*  p;
+    float*  Rrho;
+    float*  m;
+} sph_fields;
+
+/* The reference's file-scope run state (WCXSPH3D.cpp:70-71,76-79). */
+typedef struct sph_scalars {
+    double dt;
+    float  t;
+    double maxmu, maxf, errsum, logbase;
+    /* diagnostics of this implementation */
+    uint64_t list_rebuilds;   /* neighbour-candidate rebuilds so far */
+    uint64_t step_redos;      /* steps repeated because a particle outran the skin */
+} sph_scalars;
+
+typedef struct sph_ctx sph_ctx;
+
+/* Replaces the construction of both State vectors and the kd-tree in main()
+ * (WCXSPH3D.cpp:444-454).  Allocates device memory for params->npts particles. */
+int sph_create(const sph_params* params, sph_ctx** out);
+void sph_destroy(sph_ctx* ctx);
+const char* sph_last_error(const sph_ctx* ctx);
+
+/* Host -> device copy of one State (what InitSPH and the particlesh copy loop fill:
+ * WCXSPH3D.cpp:448-451).  Components beyond dim are ignored. */
+int sph_upload(sph_ctx* ctx, int32_t which_state, const sph_fields* src);
+/* Device -> host copy of one State in original order (what write_frame_data reads:
+ * WCXSPH3D.cpp:408-437). */
+int sph_download(sph_ctx* ctx, int32_t which_state, const sph_fields* dst);
+
+/* Forces(State&, tree) on one state (WCXSPH3D.cpp:139-205; WCXSPH.cpp:134-201;
+ * WCSPH.cpp:137-200), including the fixed-radius search it performs per particle. */
+int sph_forces(sph_ctx* ctx, int32_t which_state);
+/* The loop after the t=0 Forces call that zeroes the wall particles' f
+ * (WCXSPH3D.cpp:457-458). */
+int sph_zero_boundary_forces(sph_ctx* ctx, int32_t which_state);
+
+/* nsteps x Newmark_Beta(particles, particlesh, tree) (WCXSPH3D.cpp:251-303;
+ * WCXSPH.cpp:245-298; WCSPH.cpp:245-296).  `out` may be NULL. */
+int sph_step(sph_ctx* ctx, int32_t nsteps, sph_scalars* out);
+/* Diagnostic: the first `nsweeps` sweeps (Forces + wall reset + update) of ONE
+ * Newmark_Beta call, without the time-step update and without the pn = pnp1 copy, and with
+ * f, V and Rrho of state n+1 stored after the last of them. */
+int sph_sweeps(sph_ctx* ctx, int32_t nsweeps, sph_scalars* out);
+
+int sph_get_scalars(sph_ctx* ctx, sph_scalars* out);
+int sph_set_dt(sph_ctx* ctx, double dt);
+
+/* DensityReinit(particlesh, tree) (WCXSPH3D.cpp:208-249). */
+int sph_density_reinit(sph_ctx* ctx);
+
+/* The fixed-radius neighbour sets that Forces() would see for one state, as CSR over
+ * original indices, columns ascending, the particle itself included (the result of
+ * radiusSearch at WCXSPH3D.cpp:157 for every particle).  row_offsets has npts+1 entries.
+ * With cols == NULL only row_offsets is filled. */
+int sph_neighbours(sph_ctx* ctx, int32_t which_state, uint64_t* row_offsets, uint32_t* cols);
+
+/* ---- timing of the pair kernel, for benchmarks ------------------------------------- */
+/* When enabled, every launch of the fused pair/update kernel is bracketed by HIP events
+ * on the context's stream. sph_profile_read returns the summed duration and launch count
+ * since the last read, waiting for the stream first. */
+int sph_profile_enable(sph_ctx* ctx, int32_t on);
+int sph_profile_read(sph_ctx* ctx, double* pair_ms_total, uint64_t* pair_launches,
+                     double* rebuild_ms_total, uint64_t* rebuilds);
+
+/* ---- the reference's case set-up, host side ----------------------------------------- */
+/* The "Simulation Definition" block (WCXSPH3D.cpp:39-48; WCXSPH.cpp:36-45; WCSPH.cpp:42-51). */
+enum { SPH_PROGRAM_WCSPH = 0, SPH_PROGRAM_WCXSPH = 1, SPH_PROGRAM_WCXSPH3D = 2 };
+typedef struct sph_case {
+    int32_t program;     /* SPH_PROGRAM_* */
+    int32_t npart[3];    /* xyPART */
+    double  pstep;       /* Pstep */
+    double  box[3];      /* Box */
+    double  start[3];    /* Start */
+    double  dt0;         /* initial dt */
+} sph_case;
+
+/* The constants as shipped in the given reference program. */
+int sph_case_default(int32_t program, sph_case* out);
+/* Derived constants in the reference's operation order, plus particle counts. */
+int sph_case_params(const sph_case* c, sph_params* out, double* simmass, double* boundmass);
+/* InitSPH (WCXSPH3D.cpp:306-379; WCXSPH.cpp:301-350; WCSPH.cpp:297-350): fills x, v, V, f,
+ * rho, p, Rrho, m of `dst` (arrays of params.npts entries; NULL entries skipped). */
+int sph_case_init(const sph_case* c, const sph_fields* dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,282 @@
+"""ctypes binding of libsph_amd.so (include/sph_amd.h) and a thin host-side mirror of the
+reference's driver objects: `Sim` owns one context and speaks in the reference's terms
+(`particles` = state n, `particlesh` = state n+1, Forces, Newmark_Beta, DensityReinit).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present, loading or
+creating a context raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsph_amd.so")
+
+OK, EINVAL, EDEVICE, ENOMEM, ESTATE, ECOMM = range(6)
+VARIANT_WCSPH, VARIANT_WCXSPH = 0, 1
+STATE_N, STATE_NP1 = 0, 1
+PROGRAM_WCSPH, PROGRAM_WCXSPH, PROGRAM_WCXSPH3D = 0, 1, 2
+
+# every symbol include/sph_amd.h declares
+SYMBOLS = (
+    "sph_create", "sph_destroy", "sph_last_error", "sph_upload", "sph_download", "sph_forces",
+    "sph_zero_boundary_forces", "sph_step", "sph_sweeps", "sph_get_scalars", "sph_set_dt",
+    "sph_density_reinit", "sph_neighbours", "sph_profile_enable", "sph_profile_read",
+    "sph_case_default", "sph_case_params", "sph_case_init",
+)
+
+
+class Params(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("variant", C.c_int32), ("npts", C.c_uint64),
+                ("bound_parts", C.c_uint64), ("H", C.c_double), ("HSQ", C.c_double),
+                ("correc", C.c_double), ("search_radius_sq", C.c_double), ("B", C.c_double),
+                ("gam", C.c_double), ("rho0", C.c_double), ("Cs", C.c_double),
+                ("alpha", C.c_double), ("eps", C.c_double), ("g", C.c_double),
+                ("g_axis", C.c_int32), ("subits", C.c_int32), ("beta", C.c_double),
+                ("mass", C.c_double), ("dt0", C.c_double), ("skin_frac", C.c_double),
+                ("max_neighbours", C.c_int32), ("device", C.c_int32)]
+
+
+class Fields(C.Structure):
+    _fields_ = [("x", C.c_void_p * 3), ("v", C.c_void_p * 3), ("V", C.c_void_p * 3),
+                ("f", C.c_void_p * 3), ("rho", C.c_void_p), ("p", C.c_void_p),
+                ("Rrho", C.c_void_p), ("m", C.c_void_p)]
+
+
+class Scalars(C.Structure):
+    _fields_ = [("dt", C.c_double), ("t", C.c_float), ("maxmu", C.c_double), ("maxf", C.c_double),
+                ("errsum", C.c_double), ("logbase", C.c_double), ("list_rebuilds", C.c_uint64),
+                ("step_redos", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Case(C.Structure):
+    _fields_ = [("program", C.c_int32), ("npart", C.c_int32 * 3), ("pstep", C.c_double),
+                ("box", C.c_double * 3), ("start", C.c_double * 3), ("dt0", C.c_double)]
+
+
+class SphError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libsph_amd.so; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SphError("libsph_amd.so is not built (run `make -C sph_amd/csrc` or "
+                       "__graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.sph_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.sph_destroy.argtypes = [vp]
+    L.sph_destroy.restype = None
+    L.sph_last_error.argtypes = [vp]
+    L.sph_last_error.restype = C.c_char_p
+    L.sph_upload.argtypes = [vp, C.c_int32, C.POINTER(Fields)]
+    L.sph_download.argtypes = [vp, C.c_int32, C.POINTER(Fields)]
+    L.sph_forces.argtypes = [vp, C.c_int32]
+    L.sph_zero_boundary_forces.argtypes = [vp, C.c_int32]
+    L.sph_step.argtypes = [vp, C.c_int32, C.POINTER(Scalars)]
+    L.sph_sweeps.argtypes = [vp, C.c_int32, C.POINTER(Scalars)]
+    L.sph_get_scalars.argtypes = [vp, C.POINTER(Scalars)]
+    L.sph_set_dt.argtypes = [vp, C.c_double]
+    L.sph_density_reinit.argtypes = [vp]
+    L.sph_neighbours.argtypes = [vp, C.c_int32, vp, vp]
+    L.sph_profile_enable.argtypes = [vp, C.c_int32]
+    L.sph_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.sph_case_default.argtypes = [C.c_int32, C.POINTER(Case)]
+    L.sph_case_params.argtypes = [C.POINTER(Case), C.POINTER(Params), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double)]
+    L.sph_case_init.argtypes = [C.POINTER(Case), C.POINTER(Fields)]
+    _lib = L
+    return L
+
+
+# ---------------------------------------------------------------------------------------------
+# cases
+
+
+def default_case(program):
+    c = Case()
+    if lib().sph_case_default(program, C.byref(c)) != OK:
+        raise SphError("unknown program %r" % (program,))
+    return c
+
+
+def make_case(program, npart, pstep, box, start, dt0=0.0002):
+    c = Case()
+    c.program = program
+    for d in range(3):
+        c.npart[d] = int(npart[d]) if d < len(npart) else 1
+        c.box[d] = float(box[d]) if d < len(box) else 0.0
+        c.start[d] = float(start[d]) if d < len(start) else 0.0
+    c.pstep = float(pstep)
+    c.dt0 = float(dt0)
+    return c
+
+
+def case_params(case):
+    p = Params()
+    sm, bm = C.c_double(), C.c_double()
+    if lib().sph_case_params(C.byref(case), C.byref(p), C.byref(sm), C.byref(bm)) != OK:
+        raise SphError("invalid case")
+    return p, sm.value, bm.value
+
+
+_VEC = ("x", "v", "V", "f")
+_SCA = ("rho", "p", "Rrho", "m")
+
+
+def alloc_state(npts, dim):
+    """Host arrays of one State, component-major (x[d] is contiguous)."""
+    s = {k: np.zeros((dim, npts), np.float64) for k in _VEC}
+    s.update({k: np.zeros(npts, np.float32) for k in _SCA})
+    return s
+
+
+def _fields(state, dim, names=None):
+    f = Fields()
+    for k in _VEC:
+        a = state.get(k) if (names is None or k in names) else None
+        if a is None:
+            continue
+        assert a.dtype == np.float64 and a.flags.c_contiguous and a.shape[0] == dim
+        arr = getattr(f, k)
+        for d in range(dim):
+            arr[d] = a[d].ctypes.data
+    for k in _SCA:
+        a = state.get(k) if (names is None or k in names) else None
+        if a is None:
+            continue
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+        setattr(f, k, a.ctypes.data)
+    return f
+
+
+def case_init(case):
+    """InitSPH: returns (params, state dict in original order)."""
+    p, _, _ = case_params(case)
+    st = alloc_state(int(p.npts), p.dim)
+    f = _fields(st, p.dim)
+    if lib().sph_case_init(C.byref(case), C.byref(f)) != OK:
+        raise SphError("sph_case_init failed")
+    return p, st
+
+
+# ---------------------------------------------------------------------------------------------
+
+
+class Sim:
+    """One run on one GPU: both State vectors and the file-scope scalars of the reference."""
+
+    def __init__(self, params):
+        self.params = params
+        self.dim = params.dim
+        self.npts = int(params.npts)
+        self.bound_parts = int(params.bound_parts)
+        h = C.c_void_p()
+        rc = lib().sph_create(C.byref(params), C.byref(h))
+        self._h = h
+        if rc != OK:
+            msg = lib().sph_last_error(h).decode() if h else "sph_create failed"
+            if h:
+                lib().sph_destroy(h)
+            self._h = None
+            raise SphError("sph_create: %s (code %d)" % (msg, rc))
+
+    @classmethod
+    def from_case(cls, case, **overrides):
+        """main() up to the kd-tree construction: InitSPH, copy into particlesh."""
+        p, st = case_init(case)
+        for k, v in overrides.items():
+            setattr(p, k, v)
+        sim = cls(p)
+        sim.upload(STATE_N, st)
+        sim.upload(STATE_NP1, st)
+        return sim
+
+    def _chk(self, rc, what):
+        if rc != OK:
+            raise SphError("%s: %s (code %d)" % (what, lib().sph_last_error(self._h).decode(), rc))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, which, state, names=None):
+        st = {}
+        for k, a in state.items():
+            if a is None:
+                continue
+            st[k] = np.ascontiguousarray(a, np.float64 if k in _VEC else np.float32)
+        f = _fields(st, self.dim, names)
+        self._chk(lib().sph_upload(self._h, which, C.byref(f)), "sph_upload")
+
+    def download(self, which, names=None):
+        st = alloc_state(self.npts, self.dim)
+        f = _fields(st, self.dim, names)
+        self._chk(lib().sph_download(self._h, which, C.byref(f)), "sph_download")
+        if names is not None:
+            st = {k: v for k, v in st.items() if k in names}
+        return st
+
+    def forces(self, which):
+        self._chk(lib().sph_forces(self._h, which), "sph_forces")
+
+    def zero_boundary_forces(self, which):
+        self._chk(lib().sph_zero_boundary_forces(self._h, which), "sph_zero_boundary_forces")
+
+    def step(self, nsteps=1):
+        s = Scalars()
+        self._chk(lib().sph_step(self._h, nsteps, C.byref(s)), "sph_step")
+        return s.as_dict()
+
+    def sweeps(self, nsweeps):
+        s = Scalars()
+        self._chk(lib().sph_sweeps(self._h, nsweeps, C.byref(s)), "sph_sweeps")
+        return s.as_dict()
+
+    def scalars(self):
+        s = Scalars()
+        self._chk(lib().sph_get_scalars(self._h, C.byref(s)), "sph_get_scalars")
+        return s.as_dict()
+
+    def set_dt(self, dt):
+        self._chk(lib().sph_set_dt(self._h, dt), "sph_set_dt")
+
+    def density_reinit(self):
+        self._chk(lib().sph_density_reinit(self._h), "sph_density_reinit")
+
+    def neighbours(self, which):
+        offs = np.zeros(self.npts + 1, np.uint64)
+        self._chk(lib().sph_neighbours(self._h, which, offs.ctypes.data, None), "sph_neighbours")
+        cols = np.zeros(max(int(offs[-1]), 1), np.uint32)
+        self._chk(lib().sph_neighbours(self._h, which, offs.ctypes.data, cols.ctypes.data),
+                  "sph_neighbours")
+        return offs, cols[:int(offs[-1])]
+
+    def profile_enable(self, on=True):
+        self._chk(lib().sph_profile_enable(self._h, 1 if on else 0), "sph_profile_enable")
+
+    def profile_read(self):
+        pm, rm = C.c_double(), C.c_double()
+        pn, rn = C.c_uint64(), C.c_uint64()
+        self._chk(lib().sph_profile_read(self._h, C.byref(pm), C.byref(pn), C.byref(rm), C.byref(rn)),
+                  "sph_profile_read")
+        return dict(pair_ms=pm.value, pair_launches=pn.value, rebuild_ms=rm.value, rebuilds=rn.value)

@@ -1,0 +1,808 @@
+/* Device code of the SPH pair path for gfx950: cell hash, LDS-staged radix sort, cell table,
+ * candidate lists, the fused pair/update kernel and the small reductions around it.
+ * Included once, by sph_amd.hip. */
+#ifndef SPH_KERNELS_H
+#define SPH_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sph_types.h"
+
+#define SPH_BLOCK 256
+
+/* ------------------------------------------------------------------------------------------ */
+/* small helpers                                                                              */
+
+/* Squared distance with the exact operation order of the reference's fixed-radius search
+ * (nanoflann L2 adaptor: ((dx*dx)+dy*dy)+dz*dz, no fused multiply-add).  Membership of the
+ * neighbour set is decided on this value and must not depend on contraction. */
+__device__ __forceinline__ double dist2_exact(double dx, double dy, double dz) {
+#pragma clang fp contract(off)
+    double r = dx * dx;
+    r = r + dy * dy;
+    r = r + dz * dz;
+    return r;
+}
+
+__device__ __forceinline__ int cell_coord(double x, double lo, double inv, int n) {
+    double c = floor((x - lo) * inv);
+    c = fmax(c, 0.0);               /* NaN -> 0 */
+    c = fmin(c, (double)(n - 1));
+    return (int)c;
+}
+
+/* Cell key with x slowest and the last axis fastest, so that a slab in x is a contiguous
+ * key range and a +-1 neighbourhood in the last axis is a contiguous cell range. */
+template <int DIM>
+__device__ __forceinline__ uint32_t cell_key(const GridParams& g, int cx, int cy, int cz) {
+    if (DIM == 3) return ((uint32_t)cx * (uint32_t)g.n[1] + (uint32_t)cy) * (uint32_t)g.n[2] + (uint32_t)cz;
+    return (uint32_t)cx * (uint32_t)g.n[1] + (uint32_t)cy;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+
+/* max over non-negative doubles through their bit patterns (order-preserving for x >= 0) */
+__device__ __forceinline__ void atomic_max_nonneg(unsigned long long* addr, double v) {
+    if (v > 0.0) atomicMax(addr, (unsigned long long)__double_as_longlong(v));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* bounding box of finite positions (per-block partials; the host finishes)                   */
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_bbox(const Rec* __restrict__ rec, uint32_t n, int dim,
+                                                    double* __restrict__ part /* [grid][6] */) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x; i < n; i += gridDim.x * SPH_BLOCK) {
+        bool ok = true;
+        for (int d = 0; d < dim; ++d) ok = ok && isfinite(rec[i].x[d]);
+        if (ok)
+            for (int d = 0; d < dim; ++d) {
+                lo[d] = fmin(lo[d], rec[i].x[d]);
+                hi[d] = fmax(hi[d], rec[i].x[d]);
+            }
+    }
+    __shared__ double s[SPH_BLOCK / 64][6];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = wave_min(lo[d]);
+        hi[d] = wave_max(hi[d]);
+    }
+    if (l == 0)
+        for (int d = 0; d < 3; ++d) { s[w][d] = lo[d]; s[w][3 + d] = hi[d]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = s[0][threadIdx.x];
+        for (int k = 1; k < SPH_BLOCK / 64; ++k)
+            v = threadIdx.x < 3 ? fmin(v, s[k][threadIdx.x]) : fmax(v, s[k][threadIdx.x]);
+        part[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* cell hash                                                                                  */
+
+template <int DIM>
+__global__ __launch_bounds__(SPH_BLOCK) void k_hash(const Rec* __restrict__ rec, uint32_t n, GridParams g,
+                                                    uint32_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int cx = cell_coord(rec[i].x[0], g.lo[0], g.inv[0], g.n[0]);
+    const int cy = cell_coord(rec[i].x[1], g.lo[1], g.inv[1], g.n[1]);
+    const int cz = DIM == 3 ? cell_coord(rec[i].x[2], g.lo[2], g.inv[2], g.n[2]) : 0;
+    keys[i] = cell_key<DIM>(g, cx, cy, cz);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* exclusive scan of uint32 (three phases)                                                    */
+
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SPH_BLOCK * SCAN_ITEMS)
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+    __shared__ uint32_t wsum[SPH_BLOCK / 64];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (l >= o) inc += t;
+    }
+    if (l == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SPH_BLOCK / 64; ++k) {
+        if (k < w) base += wsum[k];
+        tot += wsum[k];
+    }
+    __syncthreads();
+    if (total) *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_scan_reduce(const uint32_t* __restrict__ in, uint32_t n,
+                                                           uint32_t* __restrict__ bsum) {
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) s += in[base + k];
+    uint32_t tot;
+    block_exclusive_scan(s, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+/* one block; turns block sums into exclusive offsets */
+__global__ __launch_bounds__(SPH_BLOCK) void k_scan_bsums(uint32_t* __restrict__ bsum, uint32_t nb) {
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += SPH_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nb ? bsum[i] : 0;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan(v, &tot);
+        if (i < nb) bsum[i] = carry + ex;
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                          uint32_t n, const uint32_t* __restrict__ bsum) {
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = base + k < n ? in[base + k] : 0;
+        s += v[k];
+    }
+    uint32_t run = block_exclusive_scan(s, nullptr) + bsum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* stable LSD radix sort of (cell key, particle index), 8 bits per pass, LDS-staged           */
+
+#define RS_ITEMS 16
+#define RS_WAVES (SPH_BLOCK / 64)
+#define RS_WCHUNK (64 * RS_ITEMS)
+#define RS_TILE (SPH_BLOCK * RS_ITEMS)
+
+/* hist[digit * nblocks + block] = number of keys of this block's tile with that digit */
+__global__ __launch_bounds__(SPH_BLOCK) void k_rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                       uint32_t* __restrict__ hist, uint32_t nblocks) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const uint32_t idx = base + r * SPH_BLOCK + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+/* Scatter pass.  Tile order is (wave, round, lane) = ascending index, each wave owning a
+ * contiguous chunk; ranks are counted in that order, so equal digits keep their order.
+ * Keys and values are first permuted inside LDS so that the global writes of one digit
+ * are contiguous. vals_in == nullptr means "identity". */
+__global__ __launch_bounds__(SPH_BLOCK) void k_rs_scatter(const uint32_t* __restrict__ keys_in,
+                                                          const uint32_t* __restrict__ vals_in,
+                                                          uint32_t* __restrict__ keys_out,
+                                                          uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                                                          const uint32_t* __restrict__ hist_scanned,
+                                                          uint32_t nblocks) {
+    __shared__ uint32_t wcnt[RS_WAVES][256];
+    __shared__ uint32_t dstart[256];
+    __shared__ uint32_t gofs[256];
+    __shared__ uint32_t skey[RS_TILE];
+    __shared__ uint32_t sval[RS_TILE];
+    __shared__ uint32_t wtot[RS_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < RS_WAVES * 256; k += SPH_BLOCK) (&wcnt[0][0])[k] = 0;
+    __syncthreads();
+
+    const uint32_t tile_base = blockIdx.x * RS_TILE;
+    const uint32_t wbase = tile_base + wave * RS_WCHUNK;
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+    volatile uint32_t* wc = wcnt[wave];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const uint32_t idx = wbase + r * 64 + lane;
+        const bool valid = idx < n;
+        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[r] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
+        const uint32_t digit = valid ? ((key[r] >> shift) & 255u) : 255u;
+        unsigned long long mask = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (digit >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            mask &= bit ? bal : ~bal;
+        }
+        const uint32_t lane_rank = __popcll(mask & ((1ull << lane) - 1ull));
+        const uint32_t group = __popcll(mask);
+        const uint32_t prev = wc[digit];
+        rank[r] = prev + lane_rank;
+        __builtin_amdgcn_wave_barrier();
+        if (lane_rank == 0) wc[digit] = prev + group;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    /* thread = digit: prefix over waves, then scan over digits */
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
+            const uint32_t c = wcnt[w][tid];
+            wcnt[w][tid] = run;
+            run += c;
+        }
+        /* exclusive scan of `run` over the 256 digits */
+        uint32_t inc = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += wtot[w];
+        const uint32_t ex = base + inc - run;
+        dstart[tid] = ex;
+        gofs[tid] = hist_scanned[tid * nblocks + blockIdx.x] - ex;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const uint32_t idx = wbase + r * 64 + lane;
+        const uint32_t digit = idx < n ? ((key[r] >> shift) & 255u) : 255u;
+        const uint32_t pos = dstart[digit] + wcnt[wave][digit] + rank[r];
+        skey[pos] = key[r];
+        sval[pos] = val[r];
+    }
+    __syncthreads();
+    const uint32_t nvalid = n - tile_base < RS_TILE ? n - tile_base : RS_TILE;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const uint32_t p = r * SPH_BLOCK + tid;
+        if (p < nvalid) {
+            const uint32_t kk = skey[p];
+            const uint32_t out = gofs[(kk >> shift) & 255u] + p;
+            keys_out[out] = kk;
+            vals_out[out] = sval[p];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* physical reorder into cell order                                                           */
+
+struct ReorderArgs {
+    const uint32_t* perm; /* new position -> old position */
+    uint32_t n;
+    int nd, nf, nr;
+    const double* sd[18];
+    double* dd[18];
+    const float* sf[5];
+    float* df[5];
+    const Rec* rs[2];
+    Rec* rd[2];
+    const uint32_t* ids;
+    uint32_t* idd;
+};
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_reorder(ReorderArgs a) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t s = a.perm[i];
+    for (int k = 0; k < a.nd; ++k) a.dd[k][i] = a.sd[k][s];
+    for (int k = 0; k < a.nf; ++k) a.df[k][i] = a.sf[k][s];
+    for (int k = 0; k < a.nr; ++k) a.rd[k][i] = a.rs[k][s];
+    a.idd[i] = a.ids[s];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* cell table: first and one-past-last sorted position of every non-empty cell                */
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_cell_mark(const uint32_t* __restrict__ keys, uint32_t n,
+                                                         uint32_t* __restrict__ cbeg, uint32_t* __restrict__ cend) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys[i];
+    if (i == 0 || keys[i - 1] != k) cbeg[k] = i;
+    if (i == n - 1 || keys[i + 1] != k) cend[k] = i + 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* candidate lists: every j != i with |xi-xj|^2 <= rl2 at build time, column-major           */
+/* (entry k of particle i at nbr[k*stride+i]), in cell-range order then ascending j.          */
+
+template <int DIM>
+__global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict__ rec, const uint32_t* __restrict__ keys,
+                                                          uint32_t n, GridParams g, const uint32_t* __restrict__ cbeg,
+                                                          const uint32_t* __restrict__ cend, double rl2,
+                                                          uint32_t* __restrict__ nbr, uint32_t stride, uint32_t cap,
+                                                          uint32_t* __restrict__ cnt, uint32_t* __restrict__ need) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double xi = rec[i].x[0], yi = rec[i].x[1], zi = DIM == 3 ? rec[i].x[2] : 0.0;
+    const uint32_t key = keys[i];
+    int cx, cy, cz = 0;
+    if (DIM == 3) {
+        cz = (int)(key % (uint32_t)g.n[2]);
+        const uint32_t t = key / (uint32_t)g.n[2];
+        cy = (int)(t % (uint32_t)g.n[1]);
+        cx = (int)(t / (uint32_t)g.n[1]);
+    } else {
+        cy = (int)(key % (uint32_t)g.n[1]);
+        cx = (int)(key / (uint32_t)g.n[1]);
+    }
+    const int nlast = DIM == 3 ? g.n[2] : g.n[1];
+    const int clast = DIM == 3 ? cz : cy;
+    const int l0 = clast > 0 ? clast - 1 : 0;
+    const int l1 = clast < nlast - 1 ? clast + 1 : nlast - 1;
+    uint32_t k = 0;
+    for (int dx = -1; dx <= 1; ++dx) {
+        const int ax = cx + dx;
+        if (ax < 0 || ax >= g.n[0]) continue;
+        for (int dy = (DIM == 3 ? -1 : 0); dy <= (DIM == 3 ? 1 : 0); ++dy) {
+            const int ay = cy + dy;
+            if (DIM == 3 && (ay < 0 || ay >= g.n[1])) continue;
+            uint32_t c0, c1;
+            if (DIM == 3) {
+                c0 = cell_key<3>(g, ax, ay, l0);
+                c1 = cell_key<3>(g, ax, ay, l1);
+            } else {
+                c0 = cell_key<2>(g, ax, l0, 0);
+                c1 = cell_key<2>(g, ax, l1, 0);
+            }
+            uint32_t b = 0xFFFFFFFFu, e = 0;
+            for (uint32_t c = c0; c <= c1; ++c) {
+                b = min(b, cbeg[c]);
+                e = max(e, cend[c]);
+            }
+            for (uint32_t j = b; j < e; ++j) {
+                if (j == i) continue;
+                const double dx_ = xi - rec[j].x[0], dy_ = yi - rec[j].x[1];
+                const double dz_ = DIM == 3 ? zi - rec[j].x[2] : 0.0;
+                const double d2 = dist2_exact(dx_, dy_, dz_);
+                if (d2 <= rl2) {
+                    if (k < cap) nbr[(size_t)k * stride + i] = j;
+                    ++k;
+                }
+            }
+        }
+    }
+    cnt[i] = k < cap ? k : cap;
+    if (k > cap) atomicMax(need, k);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the pair kernel                                                                            */
+
+struct NState { /* state n, structure of arrays, cell order */
+    const double* x[3];
+    const double* v[3];
+    const double* V[3];
+    const double* f[3];
+    const float* rho;
+    const float* Rrho;
+};
+
+struct OutState { /* f, V, Rrho produced by Forces */
+    double* f[3];
+    double* V[3];
+    float* Rrho;
+};
+
+/* (rho/rho0)^gam - 1 as the reference's pow(rho/rho0, 7.0) - 1 evaluates it: the power is
+ * rounded to double once and 1 is subtracted exactly.  The power is formed from
+ * d = x - 1 (exact for x near 1) so that its rounding matches a correctly rounded pow. */
+__device__ __forceinline__ double tait_pow_m1(double x, double gam) {
+    if (gam == 7.0) {
+        const double d = x - 1.0;
+        const double e = d * (7.0 + d * (21.0 + d * (35.0 + d * (35.0 + d * (21.0 + d * (7.0 + d))))));
+        const double pw = 1.0 + e;
+        return pw - 1.0;
+    }
+    return pow(x, gam) - 1.0;
+}
+
+/* One thread per particle of state n+1 (cell order).
+ *  Forces (WCXSPH3D.cpp:139-205): walks the candidate list, keeps pairs with
+ *  dist2_exact < search_radius, accumulates momentum, continuity, XSPH and max(mu).
+ *  FUSED additionally performs, for the same particle, the wall reset, the Newmark-beta
+ *  update with the Tait pressure and the position-change sum (WCXSPH3D.cpp:260-285),
+ *  writing the new pair-loop input into a second record array. */
+template <int DIM, bool XSPH, bool FUSED>
+__global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __restrict__ rin,
+                                                    const uint32_t* __restrict__ nbr, uint32_t stride,
+                                                    const uint32_t* __restrict__ cnt, OutState out, int store_out,
+                                                    int zero_wall, NState ns, const uint32_t* __restrict__ id,
+                                                    Rec* __restrict__ rout, DevScalars* __restrict__ S,
+                                                    double* __restrict__ err_part) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    const bool active = i < P.n;
+    double mumax = 0.0, f2 = 0.0, move2 = 0.0;
+
+    if (active) {
+        const Rec ri = rin[i];
+        const double rho_i = (double)ri.rho;
+        const double c_i = sqrt(P.Bgam / rho_i);
+        const double pr_i = (double)ri.p / (rho_i * rho_i);
+        const double invHSQ = 1.0 / P.HSQ;
+        double acc[3] = {0.0, 0.0, 0.0};
+        double Vacc[3] = {ri.v[0], ri.v[1], ri.v[2]};
+        double rr = 0.0;
+        const uint32_t c = cnt[i];
+        for (uint32_t k = 0; k < c; ++k) {
+            const uint32_t j = nbr[(size_t)k * stride + i];
+            const Rec rj = rin[j];
+            const double Rx = rj.x[0] - ri.x[0], Ry = rj.x[1] - ri.x[1];
+            const double Rz = DIM == 3 ? rj.x[2] - ri.x[2] : 0.0;
+            const double d2 = dist2_exact(Rx, Ry, Rz);
+            if (d2 < P.R2) {
+                const double Vx = rj.v[0] - ri.v[0], Vy = rj.v[1] - ri.v[1];
+                const double Vz = DIM == 3 ? rj.v[2] - ri.v[2] : 0.0;
+                const double r = sqrt(d2);
+                const double q = r / P.H;
+                double gx = 0.0, gy = 0.0, gz = 0.0, Kern = 0.0;
+                if (q < 2.0) {
+                    const double t = 1.0 - 0.5 * q;
+                    const double t2 = t * t;
+                    const double gs = 5.0 * invHSQ * (t2 * t) * P.correc;
+                    gx = Rx * gs;
+                    gy = Ry * gs;
+                    gz = Rz * gs;
+                    if (XSPH) Kern = (t2 * t2) * (2.0 * q + 1.0) * P.correc;
+                }
+                const double rho_j = (double)rj.rho;
+                const double cbar = 0.5 * (c_i + sqrt(P.Bgam / rho_j));
+                double vdotr = Vx * Rx + Vy * Ry;
+                if (DIM == 3) vdotr += Vz * Rz;
+                const double rhoij = 0.5 * (double)(ri.rho + rj.rho); /* float add, as the reference */
+                const double muij = P.H * vdotr / (r * r + P.hvisc);
+                mumax = fmax(mumax, muij);
+                const double pr_j = (double)rj.p / (rho_j * rho_j);
+                double vg = Vx * gx + Vy * gy;
+                if (DIM == 3) vg += Vz * gz;
+                if (XSPH) {
+                    double pifac = P.alpha * cbar * muij / rhoij;
+                    if (vdotr > 0.0) pifac = 0.0;
+                    const double mj = (double)rj.m;
+                    const double sc = mj * (pifac - pr_i - pr_j);
+                    acc[0] += gx * sc;
+                    acc[1] += gy * sc;
+                    if (DIM == 3) acc[2] += gz * sc;
+                    const double xs = P.eps * (mj / rhoij) * Kern;
+                    Vacc[0] += xs * Vx;
+                    Vacc[1] += xs * Vy;
+                    if (DIM == 3) Vacc[2] += xs * Vz;
+                    rr -= mj * vg;
+                } else {
+                    double pifac = -P.alpha * cbar * muij / rhoij;
+                    if (vdotr > 0.0) pifac = 0.0;
+                    const double sc = pifac + pr_i + pr_j;
+                    acc[0] -= gx * sc;
+                    acc[1] -= gy * sc;
+                    rr -= vg;
+                }
+            }
+        }
+        double f[3];
+        float Rrho_f;
+        if (XSPH) {
+            f[0] = acc[0]; f[1] = acc[1]; f[2] = acc[2];
+            Rrho_f = (float)rr;
+        } else {
+            f[0] = acc[0] * P.mass; f[1] = acc[1] * P.mass; f[2] = 0.0;
+            Rrho_f = (float)(rr * P.mass);
+        }
+        if (P.g_axis == 0) f[0] += P.g;
+        else if (P.g_axis == 1) f[1] += P.g;
+        else f[2] += P.g;
+
+        const bool wall = zero_wall && id[i] < P.bound_parts;
+        if (wall) { /* WCXSPH3D.cpp:260-264 */
+            f[0] = f[1] = f[2] = 0.0;
+            Vacc[0] = Vacc[1] = Vacc[2] = 0.0;
+        }
+        if (store_out) {
+            for (int d = 0; d < DIM; ++d) out.f[d][i] = f[d];
+            if (XSPH)
+                for (int d = 0; d < DIM; ++d) out.V[d][i] = Vacc[d];
+            out.Rrho[i] = Rrho_f;
+        }
+        if (FUSED) {
+            f2 = f[0] * f[0] + f[1] * f[1];
+            if (DIM == 3) f2 += f[2] * f[2];
+            /* WCXSPH3D.cpp:271-277 */
+            const double dt = S->dt;
+            const double hdt = 0.5 * dt;
+            const double dt2 = dt * dt;
+            const double c1 = 0.5 * dt2 * P.omb;
+            const double c2 = dt2 * P.beta;
+            Rec ro;
+            ro.x[2] = 0.0; ro.v[2] = 0.0;
+            for (int d = 0; d < DIM; ++d) {
+                const double fn = ns.f[d][i];
+                const double vn = ns.v[d][i];
+                const double adv = XSPH ? ns.V[d][i] : vn;
+                ro.v[d] = vn + hdt * (fn + f[d]);
+                ro.x[d] = ns.x[d][i] + dt * adv + c1 * fn + c2 * f[d];
+            }
+            const float rsum = ns.Rrho[i] + Rrho_f; /* float add, as the reference */
+            ro.rho = (float)((double)ns.rho[i] + hdt * (double)rsum);
+            ro.p = (float)(P.B * tait_pow_m1((double)ro.rho / P.rho0, P.gam));
+            ro.m = ri.m;
+            ro.pad = 0;
+            rout[i] = ro;
+            const double ex = ro.x[0] - ri.x[0], ey = ro.x[1] - ri.x[1];
+            const double ez = DIM == 3 ? ro.x[2] - ri.x[2] : 0.0;
+            move2 = ex * ex + ey * ey;
+            if (DIM == 3) move2 += ez * ez;
+        }
+    }
+
+    /* block reductions: max(mu), max |f|^2, max move^2, sum move^2 */
+    __shared__ double red[SPH_BLOCK / 64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double wm = wave_max(mumax);
+    if (FUSED) {
+        const double wf = wave_max(f2);
+        const double wv = wave_max(move2 == move2 ? move2 : 1e300); /* NaN moves count as huge */
+        const double ws = wave_sum(move2);
+        if (lane == 0) { red[wave][0] = wm; red[wave][1] = wf; red[wave][2] = wv; red[wave][3] = ws; }
+    } else if (lane == 0) {
+        red[wave][0] = wm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = red[0][0];
+        for (int w = 1; w < SPH_BLOCK / 64; ++w) a = fmax(a, red[w][0]);
+        atomic_max_nonneg(&S->maxmu_bits, a);
+        if (FUSED) {
+            double b = red[0][1], c2 = red[0][2], s = red[0][3];
+            for (int w = 1; w < SPH_BLOCK / 64; ++w) {
+                b = fmax(b, red[w][1]);
+                c2 = fmax(c2, red[w][2]);
+                s += red[w][3];
+            }
+            atomic_max_nonneg(&S->maxf2_bits, b);
+            atomic_max_nonneg(&S->maxmove2_bits, c2);
+            err_part[blockIdx.x] = s;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* scalars                                                                                    */
+
+/* After Forces alone: maxmu (WCXSPH3D.cpp:141,198-200). */
+__global__ void k_forces_finalize(DevScalars* S) {
+    S->maxmu = __longlong_as_double((long long)S->maxmu_bits);
+    S->maxmu_bits = 0;
+}
+
+/* Start of a Newmark_Beta call. */
+__global__ void k_step_begin(DevScalars* S) {
+    S->violation = 0;
+    S->maxmu_bits = 0;
+    S->maxf2_bits = 0;
+    S->maxmove2_bits = 0;
+}
+
+/* End of sweep k (one block): errsum in a fixed summation order, logbase, the travel bound
+ * that guards the candidate lists, and after the last sweep the new time step
+ * (WCXSPH3D.cpp:280-288, 293-298). */
+__global__ __launch_bounds__(1024) void k_sweep_finalize(DevParams P, DevScalars* S, const double* __restrict__ err_part,
+                                                         uint32_t nparts, int k, int last) {
+    __shared__ double sh[1024];
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < nparts; i += 1024) s += err_part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double errsum = sh[0];
+        S->errsum = errsum;
+        if (k == 0) S->logbase = log10(sqrt(errsum / P.npts_d));
+        const double maxmu = __longlong_as_double((long long)S->maxmu_bits);
+        const double maxf2 = __longlong_as_double((long long)S->maxf2_bits);
+        const double move2 = __longlong_as_double((long long)S->maxmove2_bits);
+        S->maxmu = maxmu;
+        S->disp += sqrt(move2);
+        /* the positions just written feed the next sweep's pair loop through lists built
+         * earlier: they are only complete while no particle has travelled more than half
+         * the skin */
+        if (!last && !(S->disp <= S->disp_limit)) S->violation = 1;
+        if (last) {
+            const double maxf = sqrt(maxf2);
+            S->maxf = maxf;
+            const double dtf = sqrt(P.H / maxf);
+            const double dtcv = P.H / (P.Cs + maxmu);
+            S->dt_next = 0.3 * fmin(dtf, dtcv);
+        }
+        S->maxmu_bits = 0;
+        S->maxf2_bits = 0;
+        S->maxmove2_bits = 0;
+    }
+}
+
+/* pn = pnp1 and t += dt (WCXSPH3D.cpp:301-302), skipped when the step has to be redone. */
+struct CommitArgs {
+    uint32_t n;
+    int dim, xsph;
+    const Rec* rec;
+    const double* pf[3];
+    const double* pV[3];
+    const float* pRrho;
+    double* nx[3];
+    double* nv[3];
+    double* nV[3];
+    double* nf[3];
+    float* nrho;
+    float* np;
+    float* nRrho;
+};
+
+__global__ __launch_bounds__(SPH_BLOCK) void k_commit(CommitArgs a, DevScalars* S) {
+    if (S->violation) return;
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const Rec r = a.rec[i];
+    for (int d = 0; d < a.dim; ++d) {
+        a.nx[d][i] = r.x[d];
+        a.nv[d][i] = r.v[d];
+        a.nf[d][i] = a.pf[d][i];
+        if (a.xsph) a.nV[d][i] = a.pV[d][i];
+    }
+    a.nrho[i] = r.rho;
+    a.np[i] = r.p;
+    a.nRrho[i] = a.pRrho[i];
+}
+
+__global__ void k_commit_scalars(DevScalars* S) {
+    if (S->violation) return;
+    S->dt = S->dt_next;
+    S->t = (float)((double)S->t + S->dt); /* float t += double dt */
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* state plumbing                                                                             */
+
+/* state n (SoA) -> pair-loop records */
+struct PackArgs {
+    uint32_t n;
+    int dim;
+    const double* x[3];
+    const double* v[3];
+    const float* rho;
+    const float* p;
+    const float* m;
+    Rec* rec;
+};
+__global__ __launch_bounds__(SPH_BLOCK) void k_pack(PackArgs a) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    Rec r;
+    for (int d = 0; d < 3; ++d) {
+        r.x[d] = d < a.dim ? a.x[d][i] : 0.0;
+        r.v[d] = d < a.dim ? a.v[d][i] : 0.0;
+    }
+    r.rho = a.rho[i];
+    r.p = a.p[i];
+    r.m = a.m[i];
+    r.pad = 0;
+    a.rec[i] = r;
+}
+
+/* host order -> cell order and back, for one component; stride in elements of T lets the
+ * same kernel address a field inside the record array */
+template <typename T>
+__global__ __launch_bounds__(SPH_BLOCK) void k_put(T* __restrict__ dst, size_t stride, const T* __restrict__ src_orig,
+                                                   const uint32_t* __restrict__ id, uint32_t n) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i < n) dst[(size_t)i * stride] = src_orig[id[i]];
+}
+template <typename T>
+__global__ __launch_bounds__(SPH_BLOCK) void k_get(const T* __restrict__ src, size_t stride, T* __restrict__ dst_orig,
+                                                   const uint32_t* __restrict__ id, uint32_t n) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i < n) dst_orig[id[i]] = src[(size_t)i * stride];
+}
+template <typename T>
+__global__ __launch_bounds__(SPH_BLOCK) void k_fill(T* __restrict__ dst, T v, uint32_t n) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+__global__ __launch_bounds__(SPH_BLOCK) void k_iota(uint32_t* __restrict__ dst, uint32_t n) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i < n) dst[i] = i;
+}
+
+/* main():457-458 -- zero f of the wall particles of one state */
+__global__ __launch_bounds__(SPH_BLOCK) void k_zero_wall_f(double* f0, double* f1, double* f2, int dim,
+                                                           const uint32_t* __restrict__ id, uint32_t n,
+                                                           uint32_t bound_parts) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= n || id[i] >= bound_parts) return;
+    f0[i] = 0.0;
+    f1[i] = 0.0;
+    if (dim == 3) f2[i] = 0.0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* neighbour-set probe: CSR over original indices                                             */
+
+template <int DIM>
+__global__ __launch_bounds__(SPH_BLOCK) void k_nbr_count(DevParams P, const Rec* __restrict__ rec,
+                                                         const uint32_t* __restrict__ nbr, uint32_t stride,
+                                                         const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
+                                                         uint32_t* __restrict__ counts_orig) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= P.n) return;
+    const double xi = rec[i].x[0], yi = rec[i].x[1], zi = DIM == 3 ? rec[i].x[2] : 0.0;
+    uint32_t hits = dist2_exact(0.0, 0.0, 0.0) < P.R2 ? 1u : 0u; /* the particle itself */
+    const uint32_t c = cnt[i];
+    for (uint32_t k = 0; k < c; ++k) {
+        const uint32_t j = nbr[(size_t)k * stride + i];
+        const double d2 = dist2_exact(rec[j].x[0] - xi, rec[j].x[1] - yi, DIM == 3 ? rec[j].x[2] - zi : 0.0);
+        if (d2 < P.R2) ++hits;
+    }
+    counts_orig[id[i]] = hits;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(SPH_BLOCK) void k_nbr_fill(DevParams P, const Rec* __restrict__ rec,
+                                                        const uint32_t* __restrict__ nbr, uint32_t stride,
+                                                        const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
+                                                        const uint64_t* __restrict__ offs, uint32_t* __restrict__ cols) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= P.n) return;
+    const double xi = rec[i].x[0], yi = rec[i].x[1], zi = DIM == 3 ? rec[i].x[2] : 0.0;
+    uint32_t* row = cols + offs[id[i]];
+    uint32_t m = 0;
+    auto insert = [&](uint32_t v) { /* insertion into the ascending row */
+        uint32_t p = m++;
+        while (p > 0 && row[p - 1] > v) {
+            row[p] = row[p - 1];
+            --p;
+        }
+        row[p] = v;
+    };
+    if (dist2_exact(0.0, 0.0, 0.0) < P.R2) insert(id[i]);
+    const uint32_t c = cnt[i];
+    for (uint32_t k = 0; k < c; ++k) {
+        const uint32_t j = nbr[(size_t)k * stride + i];
+        const double d2 = dist2_exact(rec[j].x[0] - xi, rec[j].x[1] - yi, DIM == 3 ? rec[j].x[2] - zi : 0.0);
+        if (d2 < P.R2) insert(id[j]);
+    }
+}
+
+#endif

@@ -1,0 +1,58 @@
+/* Internal device/host types shared by the kernels and the context. */
+#ifndef SPH_TYPES_H
+#define SPH_TYPES_H
+
+#include <stdint.h>
+
+/* Pair-loop input of one particle of state n+1: everything a neighbour contributes, in one
+ * 64-byte line so that a gather touches a single aligned segment.  Precisions as in the
+ * reference's struct Particle (WCXSPH3D.cpp:85-86): x, v double; rho, p, m float. */
+struct __attribute__((aligned(16))) Rec {
+    double   x[3];
+    double   v[3];
+    float    rho, p, m;
+    uint32_t pad;
+};
+static_assert(sizeof(Rec) == 64, "Rec must be one 64-byte line");
+
+/* Run constants as the kernels take them (by value). */
+struct DevParams {
+    int32_t  dim, xsph;
+    uint32_t n, bound_parts;
+    double   H, HSQ, correc, R2;
+    double   Bgam;      /* B*gam, the numerator of the sound-speed term (WCXSPH3D.cpp:172) */
+    double   B, gam, rho0, Cs;
+    double   alpha, eps, g;
+    int32_t  g_axis, subits;
+    double   beta;      /* (double)beta_f */
+    double   omb;       /* (double)(1 - 2*beta_f), evaluated in float as the reference does */
+    double   mass;
+    double   hvisc;     /* 0.01*HSQ */
+    double   npts_d;    /* 1.0*npts */
+};
+
+/* Uniform grid over the particles' bounding box. Cell edge >= candidate radius. */
+struct GridParams {
+    double   lo[3];
+    double   inv[3];
+    int32_t  n[3];
+    uint32_t ncells;
+};
+
+/* Device-resident run state: the reference's file-scope globals (WCXSPH3D.cpp:70-79) plus
+ * the accumulators of the sweep in flight. */
+struct DevScalars {
+    double dt;        /* time step in use */
+    double dt_next;   /* set by the last sweep, adopted at commit */
+    double maxmu, maxf, errsum, logbase;
+    double disp;      /* upper bound of any particle's travel since the candidate lists were built */
+    double disp_limit;
+    float  t;
+    int32_t violation;            /* a sweep started with disp > disp_limit */
+    /* accumulators, reset by the sweep-finalize kernel */
+    unsigned long long maxmu_bits, maxf2_bits, maxmove2_bits;
+    uint32_t nan_count;
+    uint32_t pad;
+};
+
+#endif
