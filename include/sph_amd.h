@@ -85,6 +85,7 @@ typedef struct sph_scalars {
     /* diagnostics of this implementation */
     uint64_t list_rebuilds;   /* neighbour-candidate rebuilds so far */
     uint64_t step_redos;      /* steps repeated because a particle outran the skin */
+    uint64_t hit_pairs;       /* i != j pairs inside the search radius in the last sweep */
 } sph_scalars;
 
 typedef struct sph_ctx sph_ctx;

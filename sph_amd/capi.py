@@ -47,7 +47,7 @@ class Fields(C.Structure):
 class Scalars(C.Structure):
     _fields_ = [("dt", C.c_double), ("t", C.c_float), ("maxmu", C.c_double), ("maxf", C.c_double),
                 ("errsum", C.c_double), ("logbase", C.c_double), ("list_rebuilds", C.c_uint64),
-                ("step_redos", C.c_uint64)]
+                ("step_redos", C.c_uint64), ("hit_pairs", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

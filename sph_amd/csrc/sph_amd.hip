@@ -428,6 +428,7 @@ void fill_scalars(sph_ctx* c, sph_scalars* out) {
     out->logbase = s.logbase;
     out->list_rebuilds = c->rebuilds;
     out->step_redos = c->redos;
+    out->hit_pairs = s.hit_pairs;
 }
 
 /* One Newmark_Beta call, or its first `nsweeps` sweeps when partial. */

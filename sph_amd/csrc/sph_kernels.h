@@ -446,6 +446,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     const bool active = i < P.n;
     double mumax = 0.0, f2 = 0.0, move2 = 0.0;
+    uint32_t hits = 0;
 
     if (active) {
         const Rec ri = rin[i];
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
             const double Rz = DIM == 3 ? rj.x[2] - ri.x[2] : 0.0;
             const double d2 = dist2_exact(Rx, Ry, Rz);
             if (d2 < P.R2) {
+                ++hits;
                 const double Vx = rj.v[0] - ri.v[0], Vy = rj.v[1] - ri.v[1];
                 const double Vz = DIM == 3 ? rj.v[2] - ri.v[2] : 0.0;
                 const double r = sqrt(d2);
@@ -567,14 +569,17 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
     }
 
     /* block reductions: max(mu), max |f|^2, max move^2, sum move^2 */
-    __shared__ double red[SPH_BLOCK / 64][4];
+    __shared__ double red[SPH_BLOCK / 64][5];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double wm = wave_max(mumax);
     if (FUSED) {
         const double wf = wave_max(f2);
         const double wv = wave_max(move2 == move2 ? move2 : 1e300); /* NaN moves count as huge */
         const double ws = wave_sum(move2);
-        if (lane == 0) { red[wave][0] = wm; red[wave][1] = wf; red[wave][2] = wv; red[wave][3] = ws; }
+        const double wh = wave_sum((double)hits);
+        if (lane == 0) {
+            red[wave][0] = wm; red[wave][1] = wf; red[wave][2] = wv; red[wave][3] = ws; red[wave][4] = wh;
+        }
     } else if (lane == 0) {
         red[wave][0] = wm;
     }
@@ -584,12 +589,14 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
         for (int w = 1; w < SPH_BLOCK / 64; ++w) a = fmax(a, red[w][0]);
         atomic_max_nonneg(&S->maxmu_bits, a);
         if (FUSED) {
-            double b = red[0][1], c2 = red[0][2], s = red[0][3];
+            double b = red[0][1], c2 = red[0][2], s = red[0][3], h = red[0][4];
             for (int w = 1; w < SPH_BLOCK / 64; ++w) {
                 b = fmax(b, red[w][1]);
                 c2 = fmax(c2, red[w][2]);
                 s += red[w][3];
+                h += red[w][4];
             }
+            atomicAdd(&S->hit_acc, (unsigned long long)h);
             atomic_max_nonneg(&S->maxf2_bits, b);
             atomic_max_nonneg(&S->maxmove2_bits, c2);
             err_part[blockIdx.x] = s;
@@ -612,6 +619,7 @@ __global__ void k_step_begin(DevScalars* S) {
     S->maxmu_bits = 0;
     S->maxf2_bits = 0;
     S->maxmove2_bits = 0;
+    S->hit_acc = 0;
 }
 
 /* End of sweep k (one block): errsum in a fixed summation order, logbase, the travel bound
@@ -651,6 +659,8 @@ __global__ __launch_bounds__(1024) void k_sweep_finalize(DevParams P, DevScalars
         S->maxmu_bits = 0;
         S->maxf2_bits = 0;
         S->maxmove2_bits = 0;
+        S->hit_pairs = S->hit_acc;
+        S->hit_acc = 0;
     }
 }
 

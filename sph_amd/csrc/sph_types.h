@@ -51,8 +51,8 @@ struct DevScalars {
     int32_t violation;            /* a sweep started with disp > disp_limit */
     /* accumulators, reset by the sweep-finalize kernel */
     unsigned long long maxmu_bits, maxf2_bits, maxmove2_bits;
-    uint32_t nan_count;
-    uint32_t pad;
+    unsigned long long hit_acc;   /* pairs inside the radius, this sweep (self excluded) */
+    unsigned long long hit_pairs; /* the same for the last finished sweep */
 };
 
 #endif
