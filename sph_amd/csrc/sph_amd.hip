@@ -27,7 +27,7 @@ struct sph_ctx {
     DevParams dp;
     int dim = 0;
     bool xsph = false;
-    uint32_t n = 0, stride = 0, nblocks = 0;
+    uint32_t n = 0, stride = 0, nblocks = 0, npairblocks = 0;
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -46,6 +46,8 @@ struct sph_ctx {
     double* pd_alt[6] = {};
     float* pRrho = nullptr;
     float* pRrho_alt = nullptr;
+    float* pp = nullptr; /* pressure of state n+1 (the records carry p/rho^2 instead) */
+    float* pp_alt = nullptr;
     uint32_t* id = nullptr;
     uint32_t* id_alt = nullptr;
 
@@ -181,17 +183,17 @@ int build_lists(sph_ctx* c, const Rec* r) {
         HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
         if (c->dim == 3)
             hipLaunchKernelGGL(k_build_list<3>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->keys, c->n,
-                               c->grid, c->cbeg, c->cend, c->r_list2, c->nbr, c->stride, c->cap_k, c->cnt, c->need);
+                               c->grid, c->cbeg, c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need);
         else
             hipLaunchKernelGGL(k_build_list<2>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->keys, c->n,
-                               c->grid, c->cbeg, c->cend, c->r_list2, c->nbr, c->stride, c->cap_k, c->cnt, c->need);
+                               c->grid, c->cbeg, c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         const uint32_t need = *c->need_host;
         if (need <= c->cap_k) return SPH_OK;
         /* some particle has more candidates than the lists hold: grow and build again */
-        const uint32_t newcap = need + need / 8 + 4;
+        const uint32_t newcap = (need + need / 8 + 7u) & ~3u;
         HIPCHK(hipFree(c->nbr));
         c->nbr = nullptr;
         CHK(dalloc(c, &c->nbr, (size_t)newcap * c->stride));
@@ -305,7 +307,9 @@ int rebuild(sph_ctx* c, int src) {
     }
     a.sf[4] = c->pRrho;
     a.df[4] = c->pRrho_alt;
-    a.nf = 5;
+    a.sf[5] = c->pp;
+    a.df[5] = c->pp_alt;
+    a.nf = 6;
     a.rs[0] = c->rec[c->b0];
     a.rd[0] = c->rec_alt;
     a.nr = 1;
@@ -327,6 +331,7 @@ int rebuild(sph_ctx* c, int src) {
     for (int q = n_nd; q < k; ++q) std::swap(c->pd[map_pd[q - n_nd]], c->pd_alt[map_pd[q - n_nd]]);
     for (int q = 0; q < 4; ++q) std::swap(c->nfl[q], c->nfl_alt[q]);
     std::swap(c->pRrho, c->pRrho_alt);
+    std::swap(c->pp, c->pp_alt);
     std::swap(c->rec[c->b0], c->rec_alt);
     std::swap(c->id, c->id_alt);
     if (spare) {
@@ -382,10 +387,10 @@ NState n_state(sph_ctx* c) {
 template <bool FUSED>
 int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out, int zero_wall) {
     NState ns = n_state(c);
-    dim3 g(c->nblocks), b(SPH_BLOCK);
+    dim3 g(c->npairblocks), b(SPH_BLOCK);
 #define LP(D, X)                                                                                               \
-    hipLaunchKernelGGL((k_pair<D, X, FUSED>), g, b, 0, c->stream, c->dp, rin, c->nbr, c->stride, c->cnt, o,    \
-                       store_out, zero_wall, ns, c->id, rout, c->S, c->err_part)
+    hipLaunchKernelGGL((k_pair<D, X, FUSED>), g, b, 0, c->stream, c->dp, rin, c->nbr, c->cap_k, c->cnt, o,     \
+                       store_out, zero_wall, ns, c->id, rout, c->pp, c->S, c->err_part)
     if (c->dim == 3) LP(3, true);
     else if (c->xsph) LP(2, true);
     else LP(2, false);
@@ -465,7 +470,7 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             CHK(launch_pair<true>(c, c->rec[cur], c->rec[nxt], out_state(c, SPH_STATE_NP1), last ? 1 : 0, 1));
             if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
             hipLaunchKernelGGL(k_sweep_finalize, dim3(1), dim3(1024), 0, c->stream, c->dp, c->S, c->err_part,
-                               c->nblocks, k, (last && !partial) ? 1 : (last ? 2 : 0));
+                               c->npairblocks, k, (last && !partial) ? 1 : (last ? 2 : 0));
             cur = nxt;
         }
         if (!partial) {
@@ -484,6 +489,7 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
                 a.nf[d] = c->nd[NF(d)];
             }
             a.pRrho = c->pRrho;
+            a.pp = c->pp;
             a.nrho = c->nfl[F_RHO];
             a.np = c->nfl[F_P];
             a.nRrho = c->nfl[F_RRHO];
@@ -563,6 +569,7 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     c->n = (uint32_t)p->npts;
     c->stride = (c->n + 63u) & ~63u;
     c->nblocks = nblk(c->n);
+    c->npairblocks = ((c->n + PAIR_PARTICLES - 1) / PAIR_PARTICLES + 7u) & ~7u; /* a multiple of the XCD count */
     if (p->skin_frac > 0) c->skin_frac = p->skin_frac;
 
     DevParams& d = c->dp;
@@ -621,6 +628,9 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     CHK(dalloc(c, &c->pRrho, n));
     CHK(dalloc(c, &c->pRrho_alt, n));
     HIPCHK(hipMemsetAsync(c->pRrho, 0, n * sizeof(float), c->stream));
+    CHK(dalloc(c, &c->pp, n));
+    CHK(dalloc(c, &c->pp_alt, n));
+    HIPCHK(hipMemsetAsync(c->pp, 0, n * sizeof(float), c->stream));
     CHK(dalloc(c, &c->id, n));
     CHK(dalloc(c, &c->id_alt, n));
     hipLaunchKernelGGL(k_iota, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, c->id, c->n);
@@ -632,6 +642,7 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     CHK(dalloc(c, &c->cbeg, c->cell_cap));
     CHK(dalloc(c, &c->cend, c->cell_cap));
     c->cap_k = p->max_neighbours > 0 ? (uint32_t)p->max_neighbours : (c->dim == 3 ? 96u : 40u);
+    c->cap_k = (c->cap_k + 3u) & ~3u;
     CHK(dalloc(c, &c->nbr, (size_t)c->cap_k * c->stride));
     CHK(dalloc(c, &c->cnt, n));
     CHK(dalloc(c, &c->need, 1));
@@ -639,7 +650,7 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     HIPCHK(hipHostMalloc((void**)&c->S_host, sizeof(DevScalars)));
     HIPCHK(hipHostMalloc((void**)&c->bbox_host, sizeof(double) * 6 * BBOX_BLOCKS));
     HIPCHK(hipHostMalloc((void**)&c->need_host, sizeof(uint32_t)));
-    CHK(dalloc(c, &c->err_part, c->nblocks));
+    CHK(dalloc(c, &c->err_part, c->npairblocks));
     CHK(dalloc(c, &c->bbox_part, (size_t)6 * BBOX_BLOCKS));
     HIPCHK(hipMalloc(&c->tmp, n * 8));
 
@@ -669,7 +680,7 @@ void sph_destroy(sph_ctx* c) {
         if (c->pd[q]) (void)hipFree(c->pd[q]);
         if (c->pd_alt[q]) (void)hipFree(c->pd_alt[q]);
     }
-    void* ptrs[] = {c->pRrho, c->pRrho_alt, c->id,   c->id_alt, c->keys, c->keys_alt, c->perm,     c->perm_alt,
+    void* ptrs[] = {c->pp, c->pp_alt, c->pRrho, c->pRrho_alt, c->id,   c->id_alt, c->keys, c->keys_alt, c->perm,     c->perm_alt,
                     c->hist,  c->bsum,      c->cbeg, c->cend,   c->nbr,  c->cnt,      c->need,     c->S,
                     c->err_part, c->bbox_part, c->tmp};
     for (void* p : ptrs)
@@ -704,17 +715,22 @@ int sph_upload(sph_ctx* c, int32_t which, const sph_fields* s) {
         Rec* r = c->rec[c->b0];
         for (int d = 0; d < dim; ++d) {
             if (s->x[d]) {
-                CHK(put_component<double>(c, &r->x[d], 8, s->x[d]));
+                CHK(put_component<double>(c, &r->xv[d][0], 8, s->x[d]));
                 c->list_valid = false;
             }
-            if (s->v[d]) CHK(put_component<double>(c, &r->v[d], 8, s->v[d]));
+            if (s->v[d]) CHK(put_component<double>(c, &r->xv[d][1], 8, s->v[d]));
             if (s->f[d]) CHK(put_component<double>(c, c->pd[d], 1, s->f[d]));
             if (s->V[d] && c->xsph) CHK(put_component<double>(c, c->pd[3 + d], 1, s->V[d]));
         }
         if (s->rho) CHK(put_component<float>(c, &r->rho, 16, s->rho));
-        if (s->p) CHK(put_component<float>(c, &r->p, 16, s->p));
+        if (s->p) CHK(put_component<float>(c, c->pp, 1, s->p));
         if (s->m) CHK(put_component<float>(c, &r->m, 16, s->m));
         if (s->Rrho) CHK(put_component<float>(c, c->pRrho, 1, s->Rrho));
+        if (s->rho || s->p) {
+            hipLaunchKernelGGL(k_fix_prr, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->pp, c->n);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
         c->uploaded_np1 = true;
     }
     return SPH_OK;
@@ -739,13 +755,13 @@ int sph_download(sph_ctx* c, int32_t which, const sph_fields* s) {
     } else {
         const Rec* r = c->rec[c->b0];
         for (int d = 0; d < dim; ++d) {
-            if (s->x[d]) CHK(get_component<double>(c, &r->x[d], 8, s->x[d]));
-            if (s->v[d]) CHK(get_component<double>(c, &r->v[d], 8, s->v[d]));
+            if (s->x[d]) CHK(get_component<double>(c, &r->xv[d][0], 8, s->x[d]));
+            if (s->v[d]) CHK(get_component<double>(c, &r->xv[d][1], 8, s->v[d]));
             if (s->f[d]) CHK(get_component<double>(c, c->pd[d], 1, s->f[d]));
             if (s->V[d] && c->xsph) CHK(get_component<double>(c, c->pd[3 + d], 1, s->V[d]));
         }
         if (s->rho) CHK(get_component<float>(c, &r->rho, 16, s->rho));
-        if (s->p) CHK(get_component<float>(c, &r->p, 16, s->p));
+        if (s->p) CHK(get_component<float>(c, c->pp, 1, s->p));
         if (s->m) CHK(get_component<float>(c, &r->m, 16, s->m));
         if (s->Rrho) CHK(get_component<float>(c, c->pRrho, 1, s->Rrho));
     }
@@ -849,10 +865,10 @@ int sph_neighbours(sph_ctx* c, int32_t which, uint64_t* row_offsets, uint32_t* c
     uint32_t* counts = (uint32_t*)c->tmp;
     if (c->dim == 3)
         hipLaunchKernelGGL(k_nbr_count<3>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], c->nbr,
-                           c->stride, c->cnt, c->id, counts);
+                           c->cap_k, c->cnt, c->id, counts);
     else
         hipLaunchKernelGGL(k_nbr_count<2>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], c->nbr,
-                           c->stride, c->cnt, c->id, counts);
+                           c->cap_k, c->cnt, c->id, counts);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> hc(n);
     HIPCHK(hipMemcpyAsync(hc.data(), counts, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
@@ -877,10 +893,10 @@ int sph_neighbours(sph_ctx* c, int32_t which, uint64_t* row_offsets, uint32_t* c
             hipSuccess) { rc = SPH_EDEVICE; break; }
         if (c->dim == 3)
             hipLaunchKernelGGL(k_nbr_fill<3>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src],
-                               c->nbr, c->stride, c->cnt, c->id, doffs, dcols);
+                               c->nbr, c->cap_k, c->cnt, c->id, doffs, dcols);
         else
             hipLaunchKernelGGL(k_nbr_fill<2>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src],
-                               c->nbr, c->stride, c->cnt, c->id, doffs, dcols);
+                               c->nbr, c->cap_k, c->cnt, c->id, doffs, dcols);
         if (hipGetLastError() != hipSuccess) { rc = SPH_EDEVICE; break; }
         if (hipMemcpyAsync(cols, dcols, sizeof(uint32_t) * off, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
             rc = SPH_EDEVICE;

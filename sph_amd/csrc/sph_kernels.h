@@ -69,11 +69,11 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_bbox(const Rec* __restrict__ rec,
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x; i < n; i += gridDim.x * SPH_BLOCK) {
         bool ok = true;
-        for (int d = 0; d < dim; ++d) ok = ok && isfinite(rec[i].x[d]);
+        for (int d = 0; d < dim; ++d) ok = ok && isfinite(rec[i].xv[d][0]);
         if (ok)
             for (int d = 0; d < dim; ++d) {
-                lo[d] = fmin(lo[d], rec[i].x[d]);
-                hi[d] = fmax(hi[d], rec[i].x[d]);
+                lo[d] = fmin(lo[d], rec[i].xv[d][0]);
+                hi[d] = fmax(hi[d], rec[i].xv[d][0]);
             }
     }
     __shared__ double s[SPH_BLOCK / 64][6];
@@ -101,9 +101,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_hash(const Rec* __restrict__ rec,
                                                     uint32_t* __restrict__ keys) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const int cx = cell_coord(rec[i].x[0], g.lo[0], g.inv[0], g.n[0]);
-    const int cy = cell_coord(rec[i].x[1], g.lo[1], g.inv[1], g.n[1]);
-    const int cz = DIM == 3 ? cell_coord(rec[i].x[2], g.lo[2], g.inv[2], g.n[2]) : 0;
+    const int cx = cell_coord(rec[i].xv[0][0], g.lo[0], g.inv[0], g.n[0]);
+    const int cy = cell_coord(rec[i].xv[1][0], g.lo[1], g.inv[1], g.n[1]);
+    const int cz = DIM == 3 ? cell_coord(rec[i].xv[2][0], g.lo[2], g.inv[2], g.n[2]) : 0;
     keys[i] = cell_key<DIM>(g, cx, cy, cz);
 }
 
@@ -305,8 +305,8 @@ struct ReorderArgs {
     int nd, nf, nr;
     const double* sd[18];
     double* dd[18];
-    const float* sf[5];
-    float* df[5];
+    const float* sf[6];
+    float* df[6];
     const Rec* rs[2];
     Rec* rd[2];
     const uint32_t* ids;
@@ -336,8 +336,10 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_cell_mark(const uint32_t* __restr
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* candidate lists: every j != i with |xi-xj|^2 <= rl2 at build time, column-major           */
-/* (entry k of particle i at nbr[k*stride+i]), in cell-range order then ascending j.          */
+/* candidate lists: every j != i with |xi-xj|^2 <= rl2 at build time, in cell-range order     */
+/* then ascending j.  One row of `stride` entries per particle: entry k of particle i sits at  */
+/* nbr[i*stride + k], so the rounds of the pair loop walk along cache lines they have already  */
+/* touched (stride is a multiple of 4: every 16-byte group is aligned).                        */
 
 template <int DIM>
 __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict__ rec, const uint32_t* __restrict__ keys,
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
                                                           uint32_t* __restrict__ cnt, uint32_t* __restrict__ need) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const double xi = rec[i].x[0], yi = rec[i].x[1], zi = DIM == 3 ? rec[i].x[2] : 0.0;
+    const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
     const uint32_t key = keys[i];
     int cx, cy, cz = 0;
     if (DIM == 3) {
@@ -385,11 +387,11 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
             }
             for (uint32_t j = b; j < e; ++j) {
                 if (j == i) continue;
-                const double dx_ = xi - rec[j].x[0], dy_ = yi - rec[j].x[1];
-                const double dz_ = DIM == 3 ? zi - rec[j].x[2] : 0.0;
+                const double dx_ = xi - rec[j].xv[0][0], dy_ = yi - rec[j].xv[1][0];
+                const double dz_ = DIM == 3 ? zi - rec[j].xv[2][0] : 0.0;
                 const double d2 = dist2_exact(dx_, dy_, dz_);
                 if (d2 <= rl2) {
-                    if (k < cap) nbr[(size_t)k * stride + i] = j;
+                    if (k < cap) nbr[(size_t)i * stride + k] = j;
                     ++k;
                 }
             }
@@ -430,152 +432,312 @@ __device__ __forceinline__ double tait_pow_m1(double x, double gam) {
     return pow(x, gam) - 1.0;
 }
 
-/* One thread per particle of state n+1 (cell order).
- *  Forces (WCXSPH3D.cpp:139-205): walks the candidate list, keeps pairs with
- *  dist2_exact < search_radius, accumulates momentum, continuity, XSPH and max(mu).
- *  FUSED additionally performs, for the same particle, the wall reset, the Newmark-beta
- *  update with the Tait pressure and the position-change sum (WCXSPH3D.cpp:260-285),
- *  writing the new pair-loop input into a second record array. */
+/* 16-byte global -> LDS copy without a register stop: every lane names its own source, the
+ * destination is the wave-uniform base plus lane*16. */
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+/* data-parallel-primitive moves inside a quad of lanes: CTRL is a quad_perm pattern */
+template <int CTRL>
+__device__ __forceinline__ int quad_perm_i(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double quad_perm_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = quad_perm_i<CTRL>((int)(b & 0xFFFFFFFFll));
+    const int hi = quad_perm_i<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+#define QP_XOR1 0xB1 /* lanes [1,0,3,2] */
+#define QP_XOR2 0x4E /* lanes [2,3,0,1] */
+__device__ __forceinline__ double quad_sum(double v) {
+    v += quad_perm_d<QP_XOR1>(v);
+    v += quad_perm_d<QP_XOR2>(v);
+    return v;
+}
+__device__ __forceinline__ double quad_max(double v) {
+    v = fmax(v, quad_perm_d<QP_XOR1>(v));
+    v = fmax(v, quad_perm_d<QP_XOR2>(v));
+    return v;
+}
+
+/* 1/x for a normal positive x, to about one unit in the last place: the hardware estimate
+ * plus two Newton steps. */
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+/* x^(-1/2) for a normal positive x */
+__device__ __forceinline__ double fast_rsq(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    double e = fma(-hx * y, y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-hx * y, y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
+
+#define PAIR_PARTICLES (SPH_BLOCK / 4)
+/* LDS staging: per wave two buffers of four 1-KiB blocks; block r is skewed by r*16 bytes so
+ * that the four lanes of a quad read four different 16-byte bank groups */
+#define PAIR_LDS_BLOCK (1024 + 64)
+#define PAIR_LDS_WAVE (2 * 4 * PAIR_LDS_BLOCK)
+
+/* Four lanes per particle of state n+1 (cell order), 16 particles per wave.
+ *
+ *  Forces (WCXSPH3D.cpp:139-205).  Each lane of a quad walks every fourth entry of the
+ *  particle's candidate list.  The four records a quad needs per round are fetched by the
+ *  quad together -- lane q copies bytes 16q..16q+15 of each, straight into LDS -- so one
+ *  wave instruction touches 16 records of 64 contiguous bytes instead of 64 scattered
+ *  16-byte pieces; each lane then reads its own record back from LDS.  Pairs with
+ *  dist2_exact < search_radius contribute momentum, continuity, XSPH and max(mu); the four
+ *  partial sums of a quad are added at the end.
+ *
+ *  FUSED: the quad then performs the wall reset, the Newmark-beta update, the Tait pressure
+ *  and the position-change sum for its particle (WCXSPH3D.cpp:260-285): lane d owns
+ *  component d (and writes chunk d of the new record), lane 3 owns rho, p and Rrho. */
 template <int DIM, bool XSPH, bool FUSED>
 __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __restrict__ rin,
                                                     const uint32_t* __restrict__ nbr, uint32_t stride,
                                                     const uint32_t* __restrict__ cnt, OutState out, int store_out,
                                                     int zero_wall, NState ns, const uint32_t* __restrict__ id,
-                                                    Rec* __restrict__ rout, DevScalars* __restrict__ S,
-                                                    double* __restrict__ err_part) {
-    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
-    const bool active = i < P.n;
-    double mumax = 0.0, f2 = 0.0, move2 = 0.0;
+                                                    Rec* __restrict__ rout, float* __restrict__ pout,
+                                                    DevScalars* __restrict__ S, double* __restrict__ err_part) {
+    __shared__ __attribute__((aligned(16))) char stage[(SPH_BLOCK / 64) * PAIR_LDS_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane & 3;
+    /* Workgroups are dealt round-robin to the eight XCDs, each with its own L2.  Give every
+     * XCD one contiguous eighth of the cell-ordered particles, so that the records a
+     * workgroup gathers are the ones its neighbours on the same L2 have just fetched.
+     * (Placement only changes speed, never results.) */
+    const uint32_t per_xcd = gridDim.x >> 3; /* the grid is a multiple of 8 */
+    const uint32_t block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t i_raw = block * PAIR_PARTICLES + (threadIdx.x >> 2);
+    const bool active = i_raw < P.n;
+    const uint32_t i = active ? i_raw : P.n - 1;
+    char* const wstage = stage + wave * PAIR_LDS_WAVE;
+
+    const Rec ri = rin[i];
+    const double xi0 = ri.xv[0][0], xi1 = ri.xv[1][0], xi2 = ri.xv[2][0];
+    const double vi0 = ri.xv[0][1], vi1 = ri.xv[1][1], vi2 = ri.xv[2][1];
+    const double rho_i = (double)ri.rho;
+    const double sqrtBgam = sqrt(P.Bgam);
+    const double c_i = sqrt(P.Bgam / rho_i);
+    const double invH = 1.0 / P.H;
+    const double gconst = 5.0 * (1.0 / P.HSQ) * P.correc;
+
+    const uint32_t c = active ? cnt[i] : 0u;
+    /* rounds of four candidates; the trip count is made wave-uniform */
+    uint32_t rounds = (c + 3u) >> 2;
+#pragma unroll
+    for (int o = 32; o >= 4; o >>= 1) rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, o));
+    rounds = __builtin_amdgcn_readfirstlane(rounds);
+
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    double Vs0 = 0.0, Vs1 = 0.0, Vs2 = 0.0;
+    double rr = 0.0, mumax = 0.0;
     uint32_t hits = 0;
 
-    if (active) {
-        const Rec ri = rin[i];
-        const double rho_i = (double)ri.rho;
-        const double c_i = sqrt(P.Bgam / rho_i);
-        const double pr_i = (double)ri.p / (rho_i * rho_i);
-        const double invHSQ = 1.0 / P.HSQ;
-        double acc[3] = {0.0, 0.0, 0.0};
-        double Vacc[3] = {ri.v[0], ri.v[1], ri.v[2]};
-        double rr = 0.0;
-        const uint32_t c = cnt[i];
-        for (uint32_t k = 0; k < c; ++k) {
-            const uint32_t j = nbr[(size_t)k * stride + i];
-            const Rec rj = rin[j];
-            const double Rx = rj.x[0] - ri.x[0], Ry = rj.x[1] - ri.x[1];
-            const double Rz = DIM == 3 ? rj.x[2] - ri.x[2] : 0.0;
-            const double d2 = dist2_exact(Rx, Ry, Rz);
-            if (d2 < P.R2) {
-                ++hits;
-                const double Vx = rj.v[0] - ri.v[0], Vy = rj.v[1] - ri.v[1];
-                const double Vz = DIM == 3 ? rj.v[2] - ri.v[2] : 0.0;
-                const double r = sqrt(d2);
-                const double q = r / P.H;
-                double gx = 0.0, gy = 0.0, gz = 0.0, Kern = 0.0;
-                if (q < 2.0) {
-                    const double t = 1.0 - 0.5 * q;
-                    const double t2 = t * t;
-                    const double gs = 5.0 * invHSQ * (t2 * t) * P.correc;
-                    gx = Rx * gs;
-                    gy = Ry * gs;
-                    gz = Rz * gs;
-                    if (XSPH) Kern = (t2 * t2) * (2.0 * q + 1.0) * P.correc;
-                }
-                const double rho_j = (double)rj.rho;
-                const double cbar = 0.5 * (c_i + sqrt(P.Bgam / rho_j));
-                double vdotr = Vx * Rx + Vy * Ry;
-                if (DIM == 3) vdotr += Vz * Rz;
-                const double rhoij = 0.5 * (double)(ri.rho + rj.rho); /* float add, as the reference */
-                const double muij = P.H * vdotr / (r * r + P.hvisc);
-                mumax = fmax(mumax, muij);
-                const double pr_j = (double)rj.p / (rho_j * rho_j);
-                double vg = Vx * gx + Vy * gy;
-                if (DIM == 3) vg += Vz * gz;
-                if (XSPH) {
-                    double pifac = P.alpha * cbar * muij / rhoij;
-                    if (vdotr > 0.0) pifac = 0.0;
-                    const double mj = (double)rj.m;
-                    const double sc = mj * (pifac - pr_i - pr_j);
-                    acc[0] += gx * sc;
-                    acc[1] += gy * sc;
-                    if (DIM == 3) acc[2] += gz * sc;
-                    const double xs = P.eps * (mj / rhoij) * Kern;
-                    Vacc[0] += xs * Vx;
-                    Vacc[1] += xs * Vy;
-                    if (DIM == 3) Vacc[2] += xs * Vz;
-                    rr -= mj * vg;
-                } else {
-                    double pifac = -P.alpha * cbar * muij / rhoij;
-                    if (vdotr > 0.0) pifac = 0.0;
-                    const double sc = pifac + pr_i + pr_j;
-                    acc[0] -= gx * sc;
-                    acc[1] -= gy * sc;
-                    rr -= vg;
-                }
-            }
+    /* The candidate row of particle i: entry e at nbr[i*cap + e].  Every fourth round each
+     * lane fetches 16 bytes of it: lane q holds the four candidates of round 4u+q. */
+    const uint32_t* const row = nbr + (size_t)i * stride;
+    auto fetch_vec = [&](uint32_t u) -> uint4 {
+        const uint32_t e = u * 16u + (uint32_t)q * 4u;
+        uint4 v = make_uint4(i, i, i, i);
+        if (e < c) {
+            v = *(const uint4*)(row + e);
+            if (e + 1 >= c) v.y = i; /* slots past the count hold no index */
+            if (e + 2 >= c) v.z = i;
+            if (e + 3 >= c) v.w = i;
         }
-        double f[3];
-        float Rrho_f;
-        if (XSPH) {
-            f[0] = acc[0]; f[1] = acc[1]; f[2] = acc[2];
-            Rrho_f = (float)rr;
-        } else {
-            f[0] = acc[0] * P.mass; f[1] = acc[1] * P.mass; f[2] = 0.0;
-            Rrho_f = (float)(rr * P.mass);
-        }
-        if (P.g_axis == 0) f[0] += P.g;
-        else if (P.g_axis == 1) f[1] += P.g;
-        else f[2] += P.g;
+        return v;
+    };
+    auto stage4 = [&](uint32_t j0, uint32_t j1, uint32_t j2, uint32_t j3, uint32_t t) {
+        char* base = wstage + (t & 1u) * (4 * PAIR_LDS_BLOCK);
+        dma16((const char*)(rin + j0) + 16 * q, base);
+        dma16((const char*)(rin + j1) + 16 * q, base + 1 * PAIR_LDS_BLOCK + 16);
+        dma16((const char*)(rin + j2) + 16 * q, base + 2 * PAIR_LDS_BLOCK + 32);
+        dma16((const char*)(rin + j3) + 16 * q, base + 3 * PAIR_LDS_BLOCK + 48);
+    };
+    /* stage round t, whose four candidates sit in lane (t & 3) of the quad */
+#define STAGE_FROM(VEC, R, T)                                                                        \
+    stage4((uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).x), (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).y), \
+           (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).z), (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).w), (T))
 
-        const bool wall = zero_wall && id[i] < P.bound_parts;
-        if (wall) { /* WCXSPH3D.cpp:260-264 */
-            f[0] = f[1] = f[2] = 0.0;
-            Vacc[0] = Vacc[1] = Vacc[2] = 0.0;
-        }
-        if (store_out) {
-            for (int d = 0; d < DIM; ++d) out.f[d][i] = f[d];
-            if (XSPH)
-                for (int d = 0; d < DIM; ++d) out.V[d][i] = Vacc[d];
-            out.Rrho[i] = Rrho_f;
-        }
-        if (FUSED) {
-            f2 = f[0] * f[0] + f[1] * f[1];
-            if (DIM == 3) f2 += f[2] * f[2];
-            /* WCXSPH3D.cpp:271-277 */
-            const double dt = S->dt;
-            const double hdt = 0.5 * dt;
-            const double dt2 = dt * dt;
-            const double c1 = 0.5 * dt2 * P.omb;
-            const double c2 = dt2 * P.beta;
-            Rec ro;
-            ro.x[2] = 0.0; ro.v[2] = 0.0;
-            for (int d = 0; d < DIM; ++d) {
-                const double fn = ns.f[d][i];
-                const double vn = ns.v[d][i];
-                const double adv = XSPH ? ns.V[d][i] : vn;
-                ro.v[d] = vn + hdt * (fn + f[d]);
-                ro.x[d] = ns.x[d][i] + dt * adv + c1 * fn + c2 * f[d];
+    auto pair_term = [&](uint32_t t) {
+        const bool valid = t * 4u + (uint32_t)q < c;
+        const Rec rj = *(const Rec*)(wstage + (t & 1u) * (4 * PAIR_LDS_BLOCK) + q * PAIR_LDS_BLOCK + q * 16 +
+                                     (lane >> 2) * 64);
+        const double Rx = rj.xv[0][0] - xi0, Ry = rj.xv[1][0] - xi1;
+        const double Rz = DIM == 3 ? rj.xv[2][0] - xi2 : 0.0;
+        const double d2 = dist2_exact(Rx, Ry, Rz);
+        if (valid && d2 < P.R2) {
+            ++hits;
+            const double Vx = rj.xv[0][1] - vi0, Vy = rj.xv[1][1] - vi1;
+            const double Vz = DIM == 3 ? rj.xv[2][1] - vi2 : 0.0;
+            const double r = sqrt(d2);
+            const double qq = r * invH;
+            double gs = 0.0, Kern = 0.0;
+            if (qq < 2.0) {
+                const double t1 = 1.0 - 0.5 * qq;
+                const double t2 = t1 * t1;
+                gs = gconst * (t2 * t1);
+                if (XSPH) Kern = (t2 * t2) * (2.0 * qq + 1.0) * P.correc;
             }
-            const float rsum = ns.Rrho[i] + Rrho_f; /* float add, as the reference */
-            ro.rho = (float)((double)ns.rho[i] + hdt * (double)rsum);
-            ro.p = (float)(P.B * tait_pow_m1((double)ro.rho / P.rho0, P.gam));
-            ro.m = ri.m;
-            ro.pad = 0;
-            rout[i] = ro;
-            const double ex = ro.x[0] - ri.x[0], ey = ro.x[1] - ri.x[1];
-            const double ez = DIM == 3 ? ro.x[2] - ri.x[2] : 0.0;
-            move2 = ex * ex + ey * ey;
-            if (DIM == 3) move2 += ez * ez;
+            const double gx = Rx * gs, gy = Ry * gs, gz = Rz * gs;
+            const double rho_j = (double)rj.rho;
+            const double cbar = 0.5 * (c_i + sqrtBgam * fast_rsq(rho_j));
+            double vdotr = Vx * Rx + Vy * Ry;
+            if (DIM == 3) vdotr += Vz * Rz;
+            const double rhoij = 0.5 * (double)(ri.rho + rj.rho); /* float add, as the reference */
+            const double den = d2 + P.hvisc;
+            const double iw = fast_rcp(den * rhoij);
+            const double inv_rho = iw * den;
+            const double muij = P.H * vdotr * (iw * rhoij);
+            mumax = fmax(mumax, muij);
+            double vg = Vx * gx + Vy * gy;
+            if (DIM == 3) vg += Vz * gz;
+            if (XSPH) {
+                double pifac = P.alpha * cbar * muij * inv_rho;
+                if (vdotr > 0.0) pifac = 0.0;
+                const double mj = (double)rj.m;
+                const double sc = mj * (pifac - ri.prr - rj.prr);
+                acc0 += gx * sc;
+                acc1 += gy * sc;
+                if (DIM == 3) acc2 += gz * sc;
+                const double xs = P.eps * (mj * inv_rho) * Kern;
+                Vs0 += xs * Vx;
+                Vs1 += xs * Vy;
+                if (DIM == 3) Vs2 += xs * Vz;
+                rr -= mj * vg;
+            } else {
+                double pifac = -P.alpha * cbar * muij * inv_rho;
+                if (vdotr > 0.0) pifac = 0.0;
+                const double sc = pifac + ri.prr + rj.prr;
+                acc0 -= gx * sc;
+                acc1 -= gy * sc;
+                rr -= vg;
+            }
         }
+    };
+
+    /* Round t: wait for its records, start the copies of round t+1, then do the arithmetic
+     * of round t while they fly.  R = t & 3 is spelled out because the lane pattern of a
+     * cross-lane move is part of the instruction. */
+#define ROUND(R, NEXTVEC, NEXTR)                                          \
+    {                                                                     \
+        const uint32_t t = u * 4u + (R);                                  \
+        if (t >= rounds) break;                                           \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       \
+        if (t + 1 < rounds) STAGE_FROM(NEXTVEC, NEXTR, t + 1);            \
+        pair_term(t);                                                     \
     }
 
-    /* block reductions: max(mu), max |f|^2, max move^2, sum move^2 */
-    __shared__ double red[SPH_BLOCK / 64][5];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double wm = wave_max(mumax);
+    if (rounds > 0) {
+        uint4 vcur = fetch_vec(0);
+        STAGE_FROM(vcur, 0, 0u);
+        const uint32_t nsup = (rounds + 3u) >> 2;
+        for (uint32_t u = 0; u < nsup; ++u) {
+            uint4 vnext = make_uint4(i, i, i, i);
+            if (u + 1 < nsup) vnext = fetch_vec(u + 1);
+            ROUND(0, vcur, 1)
+            ROUND(1, vcur, 2)
+            ROUND(2, vcur, 3)
+            ROUND(3, vnext, 0)
+            vcur = vnext;
+        }
+    }
+#undef ROUND
+#undef STAGE_FROM
+
+    /* quad totals */
+    acc0 = quad_sum(acc0); acc1 = quad_sum(acc1);
+    if (DIM == 3) acc2 = quad_sum(acc2);
+    if (XSPH) {
+        Vs0 = quad_sum(Vs0); Vs1 = quad_sum(Vs1);
+        if (DIM == 3) Vs2 = quad_sum(Vs2);
+    }
+    rr = quad_sum(rr);
+    mumax = quad_max(mumax);
+
+    /* lane d finishes component d; lane 3 the scalars */
+    const bool wall = zero_wall && id[i] < P.bound_parts;
+    double f2 = 0.0, move2 = 0.0;
+    double fd = q == 0 ? acc0 : (q == 1 ? acc1 : acc2);
+    double Vd = (q == 0 ? vi0 : (q == 1 ? vi1 : vi2)) + (q == 0 ? Vs0 : (q == 1 ? Vs1 : Vs2));
+    if (!XSPH) fd *= P.mass;
+    if (q == P.g_axis) fd += P.g;
+    float Rrho_f = XSPH ? (float)rr : (float)(rr * P.mass);
+    if (wall) { /* WCXSPH3D.cpp:260-264 */
+        fd = 0.0;
+        Vd = 0.0;
+    }
+    if (q >= DIM) fd = 0.0;
+    if (active && store_out) {
+        if (q < DIM) {
+            out.f[q][i] = fd;
+            if (XSPH) out.V[q][i] = Vd;
+        } else if (q == 3) {
+            out.Rrho[i] = Rrho_f;
+        }
+    }
     if (FUSED) {
-        const double wf = wave_max(f2);
-        const double wv = wave_max(move2 == move2 ? move2 : 1e300); /* NaN moves count as huge */
-        const double ws = wave_sum(move2);
+        f2 = fd * fd;
+        /* WCXSPH3D.cpp:271-277 */
+        const double dt = S->dt;
+        const double hdt = 0.5 * dt;
+        const double dt2 = dt * dt;
+        union { double d[2]; float f[4]; } chunk;
+        if (q < DIM) {
+            const double fn = ns.f[q][i];
+            const double vn = ns.v[q][i];
+            const double adv = XSPH ? ns.V[q][i] : vn;
+            const double c1 = 0.5 * dt2 * P.omb;
+            const double c2 = dt2 * P.beta;
+            const double xnew = ns.x[q][i] + dt * adv + c1 * fn + c2 * fd;
+            chunk.d[0] = xnew;
+            chunk.d[1] = vn + hdt * (fn + fd);
+            const double ex = xnew - (q == 0 ? xi0 : (q == 1 ? xi1 : xi2));
+            move2 = ex * ex;
+        } else if (q == 3) {
+            const float rsum = ns.Rrho[i] + Rrho_f; /* float add, as the reference */
+            const float rho_new = (float)((double)ns.rho[i] + hdt * (double)rsum);
+            const float p_new = (float)(P.B * tait_pow_m1((double)rho_new / P.rho0, P.gam));
+            chunk.f[0] = rho_new;
+            chunk.f[1] = ri.m;
+            chunk.d[1] = (double)p_new / ((double)rho_new * (double)rho_new);
+            if (active) pout[i] = p_new;
+        } else { /* the unused component of a 2-D run stays zero */
+            chunk.d[0] = 0.0;
+            chunk.d[1] = 0.0;
+        }
+        if (active) {
+            double2 w;
+            w.x = chunk.d[0];
+            w.y = chunk.d[1];
+            ((double2*)(rout + i))[q] = w;
+        }
+        f2 = quad_sum(f2);
+        move2 = quad_sum(move2);
+    }
+
+    /* block reductions: max(mu), max |f|^2, max move^2, sum move^2, pair count; one lane per
+     * quad speaks for the particle */
+    __shared__ double red[SPH_BLOCK / 64][5];
+    const bool speak = active && q == 0;
+    const double wm = wave_max(speak ? mumax : 0.0);
+    if (FUSED) {
+        const double wf = wave_max(speak ? f2 : 0.0);
+        const double wv = wave_max(speak ? (move2 == move2 ? move2 : 1e300) : 0.0); /* NaN counts as huge */
+        const double ws = wave_sum(speak ? move2 : 0.0);
         const double wh = wave_sum((double)hits);
         if (lane == 0) {
             red[wave][0] = wm; red[wave][1] = wf; red[wave][2] = wv; red[wave][3] = ws; red[wave][4] = wh;
@@ -596,10 +758,10 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
                 s += red[w][3];
                 h += red[w][4];
             }
-            atomicAdd(&S->hit_acc, (unsigned long long)h);
             atomic_max_nonneg(&S->maxf2_bits, b);
             atomic_max_nonneg(&S->maxmove2_bits, c2);
-            err_part[blockIdx.x] = s;
+            atomicAdd(&S->hit_acc, (unsigned long long)h);
+            err_part[block] = s;
         }
     }
 }
@@ -669,6 +831,7 @@ struct CommitArgs {
     uint32_t n;
     int dim, xsph;
     const Rec* rec;
+    const float* pp;
     const double* pf[3];
     const double* pV[3];
     const float* pRrho;
@@ -687,13 +850,13 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_commit(CommitArgs a, DevScalars* 
     if (i >= a.n) return;
     const Rec r = a.rec[i];
     for (int d = 0; d < a.dim; ++d) {
-        a.nx[d][i] = r.x[d];
-        a.nv[d][i] = r.v[d];
+        a.nx[d][i] = r.xv[d][0];
+        a.nv[d][i] = r.xv[d][1];
         a.nf[d][i] = a.pf[d][i];
         if (a.xsph) a.nV[d][i] = a.pV[d][i];
     }
     a.nrho[i] = r.rho;
-    a.np[i] = r.p;
+    a.np[i] = a.pp[i];
     a.nRrho[i] = a.pRrho[i];
 }
 
@@ -722,14 +885,21 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pack(PackArgs a) {
     if (i >= a.n) return;
     Rec r;
     for (int d = 0; d < 3; ++d) {
-        r.x[d] = d < a.dim ? a.x[d][i] : 0.0;
-        r.v[d] = d < a.dim ? a.v[d][i] : 0.0;
+        r.xv[d][0] = d < a.dim ? a.x[d][i] : 0.0;
+        r.xv[d][1] = d < a.dim ? a.v[d][i] : 0.0;
     }
     r.rho = a.rho[i];
-    r.p = a.p[i];
     r.m = a.m[i];
-    r.pad = 0;
+    r.prr = (double)a.p[i] / ((double)r.rho * (double)r.rho);
     a.rec[i] = r;
+}
+
+/* after rho or p of state n+1 changed from outside: re-form p/rho^2 */
+__global__ __launch_bounds__(SPH_BLOCK) void k_fix_prr(Rec* __restrict__ rec, const float* __restrict__ p, uint32_t n) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double rho = (double)rec[i].rho;
+    rec[i].prr = (double)p[i] / (rho * rho);
 }
 
 /* host order -> cell order and back, for one component; stride in elements of T lets the
@@ -777,12 +947,12 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_nbr_count(DevParams P, const Rec*
                                                          uint32_t* __restrict__ counts_orig) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= P.n) return;
-    const double xi = rec[i].x[0], yi = rec[i].x[1], zi = DIM == 3 ? rec[i].x[2] : 0.0;
+    const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
     uint32_t hits = dist2_exact(0.0, 0.0, 0.0) < P.R2 ? 1u : 0u; /* the particle itself */
     const uint32_t c = cnt[i];
     for (uint32_t k = 0; k < c; ++k) {
-        const uint32_t j = nbr[(size_t)k * stride + i];
-        const double d2 = dist2_exact(rec[j].x[0] - xi, rec[j].x[1] - yi, DIM == 3 ? rec[j].x[2] - zi : 0.0);
+        const uint32_t j = nbr[(size_t)i * stride + k];
+        const double d2 = dist2_exact(rec[j].xv[0][0] - xi, rec[j].xv[1][0] - yi, DIM == 3 ? rec[j].xv[2][0] - zi : 0.0);
         if (d2 < P.R2) ++hits;
     }
     counts_orig[id[i]] = hits;
@@ -795,7 +965,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_nbr_fill(DevParams P, const Rec* 
                                                         const uint64_t* __restrict__ offs, uint32_t* __restrict__ cols) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= P.n) return;
-    const double xi = rec[i].x[0], yi = rec[i].x[1], zi = DIM == 3 ? rec[i].x[2] : 0.0;
+    const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
     uint32_t* row = cols + offs[id[i]];
     uint32_t m = 0;
     auto insert = [&](uint32_t v) { /* insertion into the ascending row */
@@ -809,8 +979,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_nbr_fill(DevParams P, const Rec* 
     if (dist2_exact(0.0, 0.0, 0.0) < P.R2) insert(id[i]);
     const uint32_t c = cnt[i];
     for (uint32_t k = 0; k < c; ++k) {
-        const uint32_t j = nbr[(size_t)k * stride + i];
-        const double d2 = dist2_exact(rec[j].x[0] - xi, rec[j].x[1] - yi, DIM == 3 ? rec[j].x[2] - zi : 0.0);
+        const uint32_t j = nbr[(size_t)i * stride + k];
+        const double d2 = dist2_exact(rec[j].xv[0][0] - xi, rec[j].xv[1][0] - yi, DIM == 3 ? rec[j].xv[2][0] - zi : 0.0);
         if (d2 < P.R2) insert(id[j]);
     }
 }

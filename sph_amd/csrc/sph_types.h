@@ -8,10 +8,10 @@
  * 64-byte line so that a gather touches a single aligned segment.  Precisions as in the
  * reference's struct Particle (WCXSPH3D.cpp:85-86): x, v double; rho, p, m float. */
 struct __attribute__((aligned(16))) Rec {
-    double   x[3];
-    double   v[3];
-    float    rho, p, m;
-    uint32_t pad;
+    double xv[3][2]; /* 16-byte chunk d = { x_d, v_d } */
+    float  rho, m;   /* chunk 3 */
+    double prr;      /* (double)p / ((double)rho*(double)rho): the reference's
+                        pi.p/pow(pi.rho,2) (WCXSPH3D.cpp:180), formed once per particle */
 };
 static_assert(sizeof(Rec) == 64, "Rec must be one 64-byte line");
 
