@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,11 +67,13 @@ struct sph_ctx {
     GridParams grid;
     bool list_valid = false;
     double skin_frac = 0.1, r_list2 = 0, disp_limit = 0;
+    uint32_t brick_log2 = 2;
     double disp_host = 0;
 
     DevScalars* S = nullptr;
     DevScalars* S_host = nullptr; /* pinned */
-    double* err_part = nullptr;
+    double* part = nullptr;  /* per-workgroup partials of the pair kernel */
+    double* part2 = nullptr; /* their first fold */
     double* bbox_part = nullptr;
     double* bbox_host = nullptr; /* pinned */
     uint32_t* need_host = nullptr;
@@ -182,10 +185,10 @@ int build_lists(sph_ctx* c, const Rec* r) {
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
         if (c->dim == 3)
-            hipLaunchKernelGGL(k_build_list<3>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->keys, c->n,
+            hipLaunchKernelGGL(k_build_list<3>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->n,
                                c->grid, c->cbeg, c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need);
         else
-            hipLaunchKernelGGL(k_build_list<2>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->keys, c->n,
+            hipLaunchKernelGGL(k_build_list<2>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->n,
                                c->grid, c->cbeg, c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -233,42 +236,46 @@ int rebuild(sph_ctx* c, int src) {
     /* cell edge: candidate radius plus a relative margin that covers the rounding of the
      * cell-coordinate arithmetic */
     const double r_list = std::sqrt(c->prm.search_radius_sq) * (1.0 + c->skin_frac);
-    double edge[3];
-    double ncell_d = 1.0;
     GridParams g;
     memset(&g, 0, sizeof g);
     for (int d = 0; d < 3; ++d) {
         g.lo[d] = 0;
         g.inv[d] = 1;
         g.n[d] = 1;
+        g.nt[d] = 1;
+        g.ts[d] = 0;
     }
-    for (int d = 0; d < dim; ++d) {
+    for (int d = 0; d < dim; ++d)
         if (!(hi[d] >= lo[d])) { lo[d] = 0; hi[d] = 0; } /* no finite particle */
-        edge[d] = r_list * (1.0 + 1e-9);
-        ncell_d *= std::floor((hi[d] - lo[d]) / edge[d]) + 1.0;
-    }
-    /* keep the table within its allocation: stretch the cells if a stray particle blew the box up */
-    const double budget = (double)c->cell_cap;
-    if (ncell_d > budget) {
-        const double s = std::pow(ncell_d / budget, 1.0 / dim) * 1.01;
-        for (int d = 0; d < dim; ++d) edge[d] *= s;
-    }
-    uint64_t ncells = 1;
-    for (int d = 0; d < dim; ++d) {
-        double cells = std::floor((hi[d] - lo[d]) / edge[d]) + 1.0;
-        while (true) {
-            uint64_t tot = 1;
-            for (int e = 0; e < d; ++e) tot *= (uint64_t)g.n[e];
-            if ((double)tot * cells <= budget || cells <= 1) break;
-            cells = std::floor(cells / 2) + 1;
-            edge[d] = (hi[d] - lo[d]) / (cells - 1) * (1.0 + 1e-9) + edge[d] * 1e-9;
+    /* bricks of 2^brick_log2 cells per axis; the grid is padded to whole bricks.  If a stray
+     * particle blew the box up, stretch the cells until the table fits its allocation. */
+    double edge = r_list * (1.0 + 1e-9);
+    uint64_t ncells = 0;
+    for (int attempt = 0; attempt < 200; ++attempt) {
+        double tot = 1.0;
+        for (int d = 0; d < dim; ++d) {
+            const double cells = std::floor((hi[d] - lo[d]) / edge) + 1.0;
+            const double tb = (double)(1u << c->brick_log2);
+            const double nt = std::ceil(cells / tb);
+            tot *= nt * tb;
         }
-        g.lo[d] = lo[d];
-        g.inv[d] = 1.0 / edge[d];
-        g.n[d] = (int)cells;
-        ncells *= (uint64_t)g.n[d];
+        if (tot <= (double)c->cell_cap && tot < 2147483648.0) {
+            ncells = 1;
+            for (int d = 0; d < dim; ++d) {
+                const double cells = std::floor((hi[d] - lo[d]) / edge) + 1.0;
+                const uint32_t tb = 1u << c->brick_log2;
+                g.ts[d] = c->brick_log2;
+                g.nt[d] = (int)std::ceil(cells / tb);
+                g.n[d] = g.nt[d] * (int)tb;
+                g.lo[d] = lo[d];
+                g.inv[d] = 1.0 / edge;
+                ncells *= (uint64_t)g.n[d];
+            }
+            break;
+        }
+        edge *= 1.26;
     }
-    if (ncells > c->cell_cap || ncells >= (1ull << 31)) return fail(c, SPH_ESTATE, "cell grid exceeds its table");
+    if (ncells == 0) return fail(c, SPH_ESTATE, "cell grid exceeds its table");
     g.ncells = (uint32_t)ncells;
     c->grid = g;
 
@@ -388,9 +395,10 @@ template <bool FUSED>
 int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out, int zero_wall) {
     NState ns = n_state(c);
     dim3 g(c->npairblocks), b(SPH_BLOCK);
+    static const int dbg = getenv("SPH_DBG") ? atoi(getenv("SPH_DBG")) : 0; /* timing experiments only */
 #define LP(D, X)                                                                                               \
     hipLaunchKernelGGL((k_pair<D, X, FUSED>), g, b, 0, c->stream, c->dp, rin, c->nbr, c->cap_k, c->cnt, o,     \
-                       store_out, zero_wall, ns, c->id, rout, c->pp, c->S, c->err_part)
+                       store_out, zero_wall, ns, c->id, rout, c->pp, c->S, c->part, dbg)
     if (c->dim == 3) LP(3, true);
     else if (c->xsph) LP(2, true);
     else LP(2, false);
@@ -469,8 +477,10 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             }
             CHK(launch_pair<true>(c, c->rec[cur], c->rec[nxt], out_state(c, SPH_STATE_NP1), last ? 1 : 0, 1));
             if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
-            hipLaunchKernelGGL(k_sweep_finalize, dim3(1), dim3(1024), 0, c->stream, c->dp, c->S, c->err_part,
-                               c->npairblocks, k, (last && !partial) ? 1 : (last ? 2 : 0));
+            hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS), dim3(SPH_BLOCK), 0, c->stream, c->part, c->npairblocks,
+                               PART_FIELDS, c->part2);
+            hipLaunchKernelGGL(k_sweep_finalize, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->part2, k,
+                               (last && !partial) ? 1 : (last ? 2 : 0));
             cur = nxt;
         }
         if (!partial) {
@@ -571,6 +581,8 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     c->nblocks = nblk(c->n);
     c->npairblocks = ((c->n + PAIR_PARTICLES - 1) / PAIR_PARTICLES + 7u) & ~7u; /* a multiple of the XCD count */
     if (p->skin_frac > 0) c->skin_frac = p->skin_frac;
+    c->brick_log2 = c->dim == 3 ? 2u : 3u;
+    if (const char* e = getenv("SPH_BRICK_LOG2")) c->brick_log2 = (uint32_t)std::min(5, std::max(0, atoi(e)));
 
     DevParams& d = c->dp;
     memset(&d, 0, sizeof d);
@@ -650,7 +662,8 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     HIPCHK(hipHostMalloc((void**)&c->S_host, sizeof(DevScalars)));
     HIPCHK(hipHostMalloc((void**)&c->bbox_host, sizeof(double) * 6 * BBOX_BLOCKS));
     HIPCHK(hipHostMalloc((void**)&c->need_host, sizeof(uint32_t)));
-    CHK(dalloc(c, &c->err_part, c->npairblocks));
+    CHK(dalloc(c, &c->part, (size_t)PART_FIELDS * c->npairblocks));
+    CHK(dalloc(c, &c->part2, (size_t)PART_FIELDS * PART_GROUPS));
     CHK(dalloc(c, &c->bbox_part, (size_t)6 * BBOX_BLOCKS));
     HIPCHK(hipMalloc(&c->tmp, n * 8));
 
@@ -682,7 +695,7 @@ void sph_destroy(sph_ctx* c) {
     }
     void* ptrs[] = {c->pp, c->pp_alt, c->pRrho, c->pRrho_alt, c->id,   c->id_alt, c->keys, c->keys_alt, c->perm,     c->perm_alt,
                     c->hist,  c->bsum,      c->cbeg, c->cend,   c->nbr,  c->cnt,      c->need,     c->S,
-                    c->err_part, c->bbox_part, c->tmp};
+                    c->part, c->part2, c->bbox_part, c->tmp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->S_host) (void)hipHostFree(c->S_host);
@@ -787,7 +800,8 @@ int sph_forces(sph_ctx* c, int32_t which) {
     }
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, c->stream, c->S);
     CHK(launch_pair<false>(c, c->rec[src], nullptr, out_state(c, which), 1, 0));
-    hipLaunchKernelGGL(k_forces_finalize, dim3(1), dim3(1), 0, c->stream, c->S);
+    hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS), dim3(SPH_BLOCK), 0, c->stream, c->part, c->npairblocks, 1, c->part2);
+    hipLaunchKernelGGL(k_forces_finalize, dim3(1), dim3(1), 0, c->stream, c->S, c->part2);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return SPH_OK;

@@ -32,12 +32,18 @@ __device__ __forceinline__ int cell_coord(double x, double lo, double inv, int n
     return (int)c;
 }
 
-/* Cell key with x slowest and the last axis fastest, so that a slab in x is a contiguous
- * key range and a +-1 neighbourhood in the last axis is a contiguous cell range. */
+/* Cell key.  Cells are grouped into bricks of 2^ts[d] cells per axis; bricks are numbered
+ * with x slowest (a slab in x is a contiguous key range) and the cells of one brick are
+ * contiguous, so that particles that follow each other in cell order are close in every
+ * direction and share most of their neighbours. */
 template <int DIM>
 __device__ __forceinline__ uint32_t cell_key(const GridParams& g, int cx, int cy, int cz) {
-    if (DIM == 3) return ((uint32_t)cx * (uint32_t)g.n[1] + (uint32_t)cy) * (uint32_t)g.n[2] + (uint32_t)cz;
-    return (uint32_t)cx * (uint32_t)g.n[1] + (uint32_t)cy;
+    const uint32_t ux = (uint32_t)cx, uy = (uint32_t)cy, uz = DIM == 3 ? (uint32_t)cz : 0u;
+    const uint32_t s0 = g.ts[0], s1 = g.ts[1], s2 = DIM == 3 ? g.ts[2] : 0u;
+    uint32_t brick = (ux >> s0) * (uint32_t)g.nt[1] + (uy >> s1);
+    if (DIM == 3) brick = brick * (uint32_t)g.nt[2] + (uz >> s2);
+    const uint32_t local = ((((ux & ((1u << s0) - 1u)) << s1) | (uy & ((1u << s1) - 1u))) << s2) | (uz & ((1u << s2) - 1u));
+    return (brick << (s0 + s1 + s2)) | local;
 }
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -54,11 +60,6 @@ __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
     return v;
-}
-
-/* max over non-negative doubles through their bit patterns (order-preserving for x >= 0) */
-__device__ __forceinline__ void atomic_max_nonneg(unsigned long long* addr, double v) {
-    if (v > 0.0) atomicMax(addr, (unsigned long long)__double_as_longlong(v));
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -342,57 +343,38 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_cell_mark(const uint32_t* __restr
 /* touched (stride is a multiple of 4: every 16-byte group is aligned).                        */
 
 template <int DIM>
-__global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict__ rec, const uint32_t* __restrict__ keys,
-                                                          uint32_t n, GridParams g, const uint32_t* __restrict__ cbeg,
+__global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict__ rec, uint32_t n, GridParams g,
+                                                          const uint32_t* __restrict__ cbeg,
                                                           const uint32_t* __restrict__ cend, double rl2,
                                                           uint32_t* __restrict__ nbr, uint32_t stride, uint32_t cap,
                                                           uint32_t* __restrict__ cnt, uint32_t* __restrict__ need) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= n) return;
     const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
-    const uint32_t key = keys[i];
-    int cx, cy, cz = 0;
-    if (DIM == 3) {
-        cz = (int)(key % (uint32_t)g.n[2]);
-        const uint32_t t = key / (uint32_t)g.n[2];
-        cy = (int)(t % (uint32_t)g.n[1]);
-        cx = (int)(t / (uint32_t)g.n[1]);
-    } else {
-        cy = (int)(key % (uint32_t)g.n[1]);
-        cx = (int)(key / (uint32_t)g.n[1]);
-    }
-    const int nlast = DIM == 3 ? g.n[2] : g.n[1];
-    const int clast = DIM == 3 ? cz : cy;
-    const int l0 = clast > 0 ? clast - 1 : 0;
-    const int l1 = clast < nlast - 1 ? clast + 1 : nlast - 1;
+    const int cx = cell_coord(xi, g.lo[0], g.inv[0], g.n[0]);
+    const int cy = cell_coord(yi, g.lo[1], g.inv[1], g.n[1]);
+    const int cz = DIM == 3 ? cell_coord(zi, g.lo[2], g.inv[2], g.n[2]) : 0;
     uint32_t k = 0;
     for (int dx = -1; dx <= 1; ++dx) {
         const int ax = cx + dx;
         if (ax < 0 || ax >= g.n[0]) continue;
-        for (int dy = (DIM == 3 ? -1 : 0); dy <= (DIM == 3 ? 1 : 0); ++dy) {
+        for (int dy = -1; dy <= 1; ++dy) {
             const int ay = cy + dy;
-            if (DIM == 3 && (ay < 0 || ay >= g.n[1])) continue;
-            uint32_t c0, c1;
-            if (DIM == 3) {
-                c0 = cell_key<3>(g, ax, ay, l0);
-                c1 = cell_key<3>(g, ax, ay, l1);
-            } else {
-                c0 = cell_key<2>(g, ax, l0, 0);
-                c1 = cell_key<2>(g, ax, l1, 0);
-            }
-            uint32_t b = 0xFFFFFFFFu, e = 0;
-            for (uint32_t c = c0; c <= c1; ++c) {
-                b = min(b, cbeg[c]);
-                e = max(e, cend[c]);
-            }
-            for (uint32_t j = b; j < e; ++j) {
-                if (j == i) continue;
-                const double dx_ = xi - rec[j].xv[0][0], dy_ = yi - rec[j].xv[1][0];
-                const double dz_ = DIM == 3 ? zi - rec[j].xv[2][0] : 0.0;
-                const double d2 = dist2_exact(dx_, dy_, dz_);
-                if (d2 <= rl2) {
-                    if (k < cap) nbr[(size_t)i * stride + k] = j;
-                    ++k;
+            if (ay < 0 || ay >= g.n[1]) continue;
+            for (int dz = (DIM == 3 ? -1 : 0); dz <= (DIM == 3 ? 1 : 0); ++dz) {
+                const int az = cz + dz;
+                if (DIM == 3 && (az < 0 || az >= g.n[2])) continue;
+                const uint32_t c = cell_key<DIM>(g, ax, ay, az);
+                const uint32_t b = cbeg[c], e = cend[c]; /* empty cell: b = 0xFFFFFFFF, e = 0 */
+                for (uint32_t j = b; j < e; ++j) {
+                    if (j == i) continue;
+                    const double dx_ = xi - rec[j].xv[0][0], dy_ = yi - rec[j].xv[1][0];
+                    const double dz_ = DIM == 3 ? zi - rec[j].xv[2][0] : 0.0;
+                    const double d2 = dist2_exact(dx_, dy_, dz_);
+                    if (d2 <= rl2) {
+                        if (k < cap) nbr[(size_t)i * stride + k] = j;
+                        ++k;
+                    }
                 }
             }
         }
@@ -430,13 +412,6 @@ __device__ __forceinline__ double tait_pow_m1(double x, double gam) {
         return pw - 1.0;
     }
     return pow(x, gam) - 1.0;
-}
-
-/* 16-byte global -> LDS copy without a register stop: every lane names its own source, the
- * destination is the wave-uniform base plus lane*16. */
-__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 /* data-parallel-primitive moves inside a quad of lanes: CTRL is a quad_perm pattern */
@@ -486,18 +461,21 @@ __device__ __forceinline__ double fast_rsq(double x) {
 }
 
 #define PAIR_PARTICLES (SPH_BLOCK / 4)
-/* LDS staging: per wave two buffers of four 1-KiB blocks; block r is skewed by r*16 bytes so
- * that the four lanes of a quad read four different 16-byte bank groups */
+/* LDS transpose area: per wave four 1-KiB blocks (one per record of a quad's round); block r
+ * is skewed by r*16 bytes so that the four lanes of a quad read four different 16-byte
+ * bank groups */
 #define PAIR_LDS_BLOCK (1024 + 64)
-#define PAIR_LDS_WAVE (2 * 4 * PAIR_LDS_BLOCK)
+#define PAIR_LDS_WAVE (4 * PAIR_LDS_BLOCK)
 
 /* Four lanes per particle of state n+1 (cell order), 16 particles per wave.
  *
  *  Forces (WCXSPH3D.cpp:139-205).  Each lane of a quad walks every fourth entry of the
  *  particle's candidate list.  The four records a quad needs per round are fetched by the
- *  quad together -- lane q copies bytes 16q..16q+15 of each, straight into LDS -- so one
- *  wave instruction touches 16 records of 64 contiguous bytes instead of 64 scattered
- *  16-byte pieces; each lane then reads its own record back from LDS.  Pairs with
+ *  quad together -- lane q loads bytes 16q..16q+15 of each -- so one wave instruction
+ *  touches 16 records of 64 contiguous bytes instead of 64 scattered 16-byte pieces (the
+ *  vector memory pipe is paced by distinct segments per instruction).  The pieces are
+ *  exchanged through a per-wave LDS area: written lane-linear, read back one whole record
+ *  per lane.  The loads of round t+1 are in flight during the arithmetic of round t.  Pairs with
  *  dist2_exact < search_radius contribute momentum, continuity, XSPH and max(mu); the four
  *  partial sums of a quad are added at the end.
  *
@@ -510,7 +488,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
                                                     const uint32_t* __restrict__ cnt, OutState out, int store_out,
                                                     int zero_wall, NState ns, const uint32_t* __restrict__ id,
                                                     Rec* __restrict__ rout, float* __restrict__ pout,
-                                                    DevScalars* __restrict__ S, double* __restrict__ err_part) {
+                                                    DevScalars* __restrict__ S, double* __restrict__ part, int dbg) {
     __shared__ __attribute__((aligned(16))) char stage[(SPH_BLOCK / 64) * PAIR_LDS_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane & 3;
@@ -549,33 +527,46 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
     /* The candidate row of particle i: entry e at nbr[i*cap + e].  Every fourth round each
      * lane fetches 16 bytes of it: lane q holds the four candidates of round 4u+q. */
     const uint32_t* const row = nbr + (size_t)i * stride;
+    /* unconditional and in bounds; entries past the count are replaced where they are used */
+    const uint32_t last_group = stride - 4u;
     auto fetch_vec = [&](uint32_t u) -> uint4 {
         const uint32_t e = u * 16u + (uint32_t)q * 4u;
-        uint4 v = make_uint4(i, i, i, i);
-        if (e < c) {
-            v = *(const uint4*)(row + e);
-            if (e + 1 >= c) v.y = i; /* slots past the count hold no index */
-            if (e + 2 >= c) v.z = i;
-            if (e + 3 >= c) v.w = i;
-        }
-        return v;
+        return *(const uint4*)(row + (e < last_group ? e : last_group));
     };
-    auto stage4 = [&](uint32_t j0, uint32_t j1, uint32_t j2, uint32_t j3, uint32_t t) {
-        char* base = wstage + (t & 1u) * (4 * PAIR_LDS_BLOCK);
-        dma16((const char*)(rin + j0) + 16 * q, base);
-        dma16((const char*)(rin + j1) + 16 * q, base + 1 * PAIR_LDS_BLOCK + 16);
-        dma16((const char*)(rin + j2) + 16 * q, base + 2 * PAIR_LDS_BLOCK + 32);
-        dma16((const char*)(rin + j3) + 16 * q, base + 3 * PAIR_LDS_BLOCK + 48);
+    /* the four pieces this lane holds of the next round's records */
+    uint4 pc0, pc1, pc2, pc3;
+    auto load4 = [&](uint32_t j0, uint32_t j1, uint32_t j2, uint32_t j3) {
+        pc0 = *(const uint4*)((const char*)(rin + j0) + 16 * q);
+        pc1 = *(const uint4*)((const char*)(rin + j1) + 16 * q);
+        pc2 = *(const uint4*)((const char*)(rin + j2) + 16 * q);
+        pc3 = *(const uint4*)((const char*)(rin + j3) + 16 * q);
     };
-    /* stage round t, whose four candidates sit in lane (t & 3) of the quad */
-#define STAGE_FROM(VEC, R, T)                                                                        \
-    stage4((uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).x), (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).y), \
-           (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).z), (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).w), (T))
+    /* load round t, whose four candidates sit in lane (t & 3) of the quad */
+#define LOAD_FROM(VEC, R, T)                                                        \
+    {                                                                               \
+        const uint32_t e0 = (T) * 4u;                                               \
+        const uint32_t a0 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).x);           \
+        const uint32_t a1 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).y);           \
+        const uint32_t a2 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).z);           \
+        const uint32_t a3 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).w);           \
+        load4(e0 < c ? a0 : i, e0 + 1u < c ? a1 : i, e0 + 2u < c ? a2 : i, e0 + 3u < c ? a3 : i); \
+    }
+    char* const my_slot = wstage + lane * 16;
+    auto exchange = [&]() -> Rec {
+        *(uint4*)(my_slot) = pc0;
+        *(uint4*)(my_slot + 1 * PAIR_LDS_BLOCK + 16) = pc1;
+        *(uint4*)(my_slot + 2 * PAIR_LDS_BLOCK + 32) = pc2;
+        *(uint4*)(my_slot + 3 * PAIR_LDS_BLOCK + 48) = pc3;
+        /* lanes of one wave run in lockstep and the LDS keeps a wave's accesses in order;
+         * only the compiler has to be kept from moving the read above the writes */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return *(const Rec*)(wstage + q * PAIR_LDS_BLOCK + q * 16 + (lane >> 2) * 64);
+    };
 
-    auto pair_term = [&](uint32_t t) {
+    auto pair_term = [&](uint32_t t, const Rec& rj) {
         const bool valid = t * 4u + (uint32_t)q < c;
-        const Rec rj = *(const Rec*)(wstage + (t & 1u) * (4 * PAIR_LDS_BLOCK) + q * PAIR_LDS_BLOCK + q * 16 +
-                                     (lane >> 2) * 64);
         const double Rx = rj.xv[0][0] - xi0, Ry = rj.xv[1][0] - xi1;
         const double Rz = DIM == 3 ? rj.xv[2][0] - xi2 : 0.0;
         const double d2 = dist2_exact(Rx, Ry, Rz);
@@ -629,25 +620,24 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
         }
     };
 
-    /* Round t: wait for its records, start the copies of round t+1, then do the arithmetic
-     * of round t while they fly.  R = t & 3 is spelled out because the lane pattern of a
-     * cross-lane move is part of the instruction. */
-#define ROUND(R, NEXTVEC, NEXTR)                                          \
-    {                                                                     \
-        const uint32_t t = u * 4u + (R);                                  \
-        if (t >= rounds) break;                                           \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       \
-        if (t + 1 < rounds) STAGE_FROM(NEXTVEC, NEXTR, t + 1);            \
-        pair_term(t);                                                     \
+    /* Round t: pass its pieces through LDS, start the loads of round t+1, then do the
+     * arithmetic of round t while they fly.  R = t & 3 is spelled out because the lane
+     * pattern of a cross-lane move is part of the instruction. */
+#define ROUND(R, NEXTVEC, NEXTR)                               \
+    {                                                          \
+        const uint32_t t = u * 4u + (R);                       \
+        if (t >= rounds) break;                                \
+        const Rec rj = exchange();                             \
+        if (t + 1 < rounds) LOAD_FROM(NEXTVEC, NEXTR, t + 1)   \
+        if (!(dbg & 2)) pair_term(t, rj);                      \
     }
 
     if (rounds > 0) {
         uint4 vcur = fetch_vec(0);
-        STAGE_FROM(vcur, 0, 0u);
+        LOAD_FROM(vcur, 0, 0u)
         const uint32_t nsup = (rounds + 3u) >> 2;
         for (uint32_t u = 0; u < nsup; ++u) {
-            uint4 vnext = make_uint4(i, i, i, i);
-            if (u + 1 < nsup) vnext = fetch_vec(u + 1);
+            const uint4 vnext = fetch_vec(u + 1);
             ROUND(0, vcur, 1)
             ROUND(1, vcur, 2)
             ROUND(2, vcur, 3)
@@ -656,7 +646,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
         }
     }
 #undef ROUND
-#undef STAGE_FROM
+#undef LOAD_FROM
 
     /* quad totals */
     acc0 = quad_sum(acc0); acc1 = quad_sum(acc1);
@@ -746,10 +736,13 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
         red[wave][0] = wm;
     }
     __syncthreads();
+    /* no atomics: with hundreds of thousands of workgroups, adds to one word serialise at the
+     * memory side.  Each workgroup leaves its five partials; two small kernels fold them. */
     if (threadIdx.x == 0) {
         double a = red[0][0];
         for (int w = 1; w < SPH_BLOCK / 64; ++w) a = fmax(a, red[w][0]);
-        atomic_max_nonneg(&S->maxmu_bits, a);
+        const uint32_t nb = gridDim.x;
+        part[block] = a;
         if (FUSED) {
             double b = red[0][1], c2 = red[0][2], s = red[0][3], h = red[0][4];
             for (int w = 1; w < SPH_BLOCK / 64; ++w) {
@@ -758,10 +751,10 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
                 s += red[w][3];
                 h += red[w][4];
             }
-            atomic_max_nonneg(&S->maxf2_bits, b);
-            atomic_max_nonneg(&S->maxmove2_bits, c2);
-            atomicAdd(&S->hit_acc, (unsigned long long)h);
-            err_part[block] = s;
+            part[nb + block] = b;
+            part[2 * (size_t)nb + block] = c2;
+            part[3 * (size_t)nb + block] = s;
+            part[4 * (size_t)nb + block] = h;
         }
     }
 }
@@ -769,60 +762,68 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
 /* ------------------------------------------------------------------------------------------ */
 /* scalars                                                                                    */
 
-/* After Forces alone: maxmu (WCXSPH3D.cpp:141,198-200). */
-__global__ void k_forces_finalize(DevScalars* S) {
-    S->maxmu = __longlong_as_double((long long)S->maxmu_bits);
-    S->maxmu_bits = 0;
-}
+#define PART_FIELDS 5   /* max mu, max |f|^2, max move^2, sum move^2, pair count */
+#define PART_GROUPS 64
 
-/* Start of a Newmark_Beta call. */
-__global__ void k_step_begin(DevScalars* S) {
-    S->violation = 0;
-    S->maxmu_bits = 0;
-    S->maxf2_bits = 0;
-    S->maxmove2_bits = 0;
-    S->hit_acc = 0;
-}
-
-/* End of sweep k (one block): errsum in a fixed summation order, logbase, the travel bound
- * that guards the candidate lists, and after the last sweep the new time step
- * (WCXSPH3D.cpp:280-288, 293-298). */
-__global__ __launch_bounds__(1024) void k_sweep_finalize(DevParams P, DevScalars* S, const double* __restrict__ err_part,
-                                                         uint32_t nparts, int k, int last) {
-    __shared__ double sh[1024];
-    double s = 0.0;
-    for (uint32_t i = threadIdx.x; i < nparts; i += 1024) s += err_part[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+/* First fold: group g reduces a fixed contiguous share of the workgroup partials, so the
+ * summation order never depends on scheduling.  part2[field*PART_GROUPS + g]. */
+__global__ __launch_bounds__(SPH_BLOCK) void k_fold_parts(const double* __restrict__ part, uint32_t nb, int nfields,
+                                                          double* __restrict__ part2) {
+    __shared__ double sh[SPH_BLOCK];
+    const uint32_t share = (nb + PART_GROUPS - 1) / PART_GROUPS;
+    const uint32_t lo = blockIdx.x * share, hi = min(nb, lo + share);
+    for (int f = 0; f < nfields; ++f) {
+        const bool is_sum = f >= 3;
+        double v = 0.0;
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += SPH_BLOCK) {
+            const double x = part[(size_t)f * nb + i];
+            v = is_sum ? v + x : fmax(v, x);
+        }
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = SPH_BLOCK / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o)
+                sh[threadIdx.x] = is_sum ? sh[threadIdx.x] + sh[threadIdx.x + o] : fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) part2[f * PART_GROUPS + blockIdx.x] = sh[0];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const double errsum = sh[0];
-        S->errsum = errsum;
-        if (k == 0) S->logbase = log10(sqrt(errsum / P.npts_d));
-        const double maxmu = __longlong_as_double((long long)S->maxmu_bits);
-        const double maxf2 = __longlong_as_double((long long)S->maxf2_bits);
-        const double move2 = __longlong_as_double((long long)S->maxmove2_bits);
-        S->maxmu = maxmu;
-        S->disp += sqrt(move2);
-        /* the positions just written feed the next sweep's pair loop through lists built
-         * earlier: they are only complete while no particle has travelled more than half
-         * the skin */
-        if (!last && !(S->disp <= S->disp_limit)) S->violation = 1;
-        if (last) {
-            const double maxf = sqrt(maxf2);
-            S->maxf = maxf;
-            const double dtf = sqrt(P.H / maxf);
-            const double dtcv = P.H / (P.Cs + maxmu);
-            S->dt_next = 0.3 * fmin(dtf, dtcv);
-        }
-        S->maxmu_bits = 0;
-        S->maxf2_bits = 0;
-        S->maxmove2_bits = 0;
-        S->hit_pairs = S->hit_acc;
-        S->hit_acc = 0;
+}
+
+__device__ __forceinline__ double fold_groups(const double* part2, int f) {
+    double v = 0.0;
+    for (int g = 0; g < PART_GROUPS; ++g) v = f >= 3 ? v + part2[f * PART_GROUPS + g] : fmax(v, part2[f * PART_GROUPS + g]);
+    return v;
+}
+
+/* After Forces alone: maxmu (WCXSPH3D.cpp:141,198-200). */
+__global__ void k_forces_finalize(DevScalars* S, const double* __restrict__ part2) { S->maxmu = fold_groups(part2, 0); }
+
+/* Start of a Newmark_Beta call. */
+__global__ void k_step_begin(DevScalars* S) { S->violation = 0; }
+
+/* End of sweep k: errsum, logbase, the travel bound that guards the candidate lists, and
+ * after the last sweep the new time step (WCXSPH3D.cpp:280-288, 293-298). */
+__global__ void k_sweep_finalize(DevParams P, DevScalars* S, const double* __restrict__ part2, int k, int last) {
+    const double maxmu = fold_groups(part2, 0);
+    const double maxf2 = fold_groups(part2, 1);
+    const double move2 = fold_groups(part2, 2);
+    const double errsum = fold_groups(part2, 3);
+    S->hit_pairs = (unsigned long long)fold_groups(part2, 4);
+    S->errsum = errsum;
+    if (k == 0) S->logbase = log10(sqrt(errsum / P.npts_d));
+    S->maxmu = maxmu;
+    S->disp += sqrt(move2);
+    /* the positions just written feed the next sweep's pair loop through lists built earlier:
+     * they are only complete while no particle has travelled more than half the skin */
+    if (!last && !(S->disp <= S->disp_limit)) S->violation = 1;
+    if (last) {
+        const double maxf = sqrt(maxf2);
+        S->maxf = maxf;
+        const double dtf = sqrt(P.H / maxf);
+        const double dtcv = P.H / (P.Cs + maxmu);
+        S->dt_next = 0.3 * fmin(dtf, dtcv);
     }
 }
 

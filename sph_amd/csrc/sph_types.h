@@ -35,7 +35,9 @@ struct DevParams {
 struct GridParams {
     double   lo[3];
     double   inv[3];
-    int32_t  n[3];
+    int32_t  n[3];    /* cells per axis, a multiple of the brick edge */
+    int32_t  nt[3];   /* bricks per axis */
+    uint32_t ts[3];   /* log2 of the brick edge in cells */
     uint32_t ncells;
 };
 
@@ -49,10 +51,7 @@ struct DevScalars {
     double disp_limit;
     float  t;
     int32_t violation;            /* a sweep started with disp > disp_limit */
-    /* accumulators, reset by the sweep-finalize kernel */
-    unsigned long long maxmu_bits, maxf2_bits, maxmove2_bits;
-    unsigned long long hit_acc;   /* pairs inside the radius, this sweep (self excluded) */
-    unsigned long long hit_pairs; /* the same for the last finished sweep */
+    unsigned long long hit_pairs; /* i != j pairs inside the radius in the last finished sweep */
 };
 
 #endif
