@@ -66,6 +66,7 @@ struct sph_ctx {
     uint32_t* need = nullptr;
     GridParams grid;
     bool list_valid = false;
+    bool lists_for_step = false; /* built by the stepping path (wall-wall pairs may be left out) */
     double skin_frac = 0.1, r_list2 = 0, disp_limit = 0;
     uint32_t brick_log2 = 2;
     double disp_host = 0;
@@ -181,15 +182,15 @@ void launch_hash(sph_ctx* c, const Rec* r) {
     hipLaunchKernelGGL(k_hash<DIM>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->n, c->grid, c->keys);
 }
 
-int build_lists(sph_ctx* c, const Rec* r) {
+int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
         if (c->dim == 3)
             hipLaunchKernelGGL(k_build_list<3>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->n,
-                               c->grid, c->cbeg, c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need);
+                               c->grid, c->cbeg, c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, c->id, wall_below);
         else
             hipLaunchKernelGGL(k_build_list<2>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->n,
-                               c->grid, c->cbeg, c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need);
+                               c->grid, c->cbeg, c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, c->id, wall_below);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -207,7 +208,7 @@ int build_lists(sph_ctx* c, const Rec* r) {
 
 /* Re-bin on the positions held in record buffer `src`, bring every live array into the new
  * cell order, rebuild cell table and candidate lists, reset the travel bound. */
-int rebuild(sph_ctx* c, int src) {
+int rebuild(sph_ctx* c, int src, bool for_step = false) {
     const uint32_t n = c->n;
     const int dim = c->dim;
     EventPair* ev = nullptr;
@@ -355,7 +356,31 @@ int rebuild(sph_ctx* c, int src) {
 
     c->r_list2 = r_list * r_list;
     c->disp_limit = 0.5 * (r_list - std::sqrt(c->prm.search_radius_sq)) * 0.999;
-    CHK(build_lists(c, c->rec[src]));
+    /* inside a step, wall-wall pairs can be dropped while the walls are at rest */
+    uint32_t wall_below = 0;
+    if (for_step && c->dp.bound_parts > 0) {
+        WallRestArgs w;
+        memset(&w, 0, sizeof w);
+        w.n = n;
+        w.wall_below = c->dp.bound_parts;
+        w.dim = dim;
+        w.xsph = c->xsph;
+        w.rec = c->rec[src];
+        for (int d = 0; d < 3; ++d) {
+            w.nv[d] = c->nd[NV(d)];
+            w.nV[d] = c->nd[NVV(d)];
+            w.nf[d] = c->nd[NF(d)];
+        }
+        w.id = c->id;
+        HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k_walls_at_rest, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, w, c->need);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (*c->need_host == 0) wall_below = c->dp.bound_parts;
+    }
+    CHK(build_lists(c, c->rec[src], wall_below));
+    c->lists_for_step = for_step;
 
     /* travel bound restarts */
     const double z[2] = {0.0, c->disp_limit};
@@ -452,14 +477,15 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
     for (int mode = 0;; ++mode) {
         /* mode 0: keep the lists if the travel budget allows; 1: fresh lists at the step's
          * start; 2: fresh lists before every sweep (exact for any motion) */
-        if (mode >= 1 || !c->list_valid || !(c->disp_host <= 0.5 * c->disp_limit)) CHK(rebuild(c, c->b0));
+        if (mode >= 1 || !c->list_valid || !c->lists_for_step || !(c->disp_host <= 0.5 * c->disp_limit))
+            CHK(rebuild(c, c->b0, true));
         hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, c->stream, c->S);
         cur = c->b0;
         for (int k = 0; k < nsweeps; ++k) {
             if (mode == 2 && k > 0) {
                 /* the start state is not needed again: let the sweep's input take its place */
                 c->b0 = cur;
-                CHK(rebuild(c, cur));
+                CHK(rebuild(c, cur, true));
             }
             int nxt = 0;
             while (nxt == cur || nxt == c->b0) ++nxt;
@@ -712,6 +738,7 @@ int sph_upload(sph_ctx* c, int32_t which, const sph_fields* s) {
     if (which != SPH_STATE_N && which != SPH_STATE_NP1) return fail(c, SPH_EINVAL, "bad state selector");
     HIPCHK(hipSetDevice(c->device));
     const int dim = c->dim;
+    c->list_valid = false; /* positions or the walls' state may change */
     if (which == SPH_STATE_N) {
         for (int d = 0; d < dim; ++d) {
             if (s->x[d]) CHK(put_component<double>(c, c->nd[NX(d)], 1, s->x[d]));

@@ -337,6 +337,34 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_cell_mark(const uint32_t* __restr
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Wall particles at rest.  Inside a Newmark-beta step the wall particles' f and V are reset    */
+/* after every Forces call (WCXSPH3D.cpp:260-264), so of everything Forces computes for a wall   */
+/* particle only Rrho and mu survive.  A pair of two wall particles adds -m*(Vij.Grad) to Rrho   */
+/* and H*(Vij.Rij)/(...) to the mu candidates: both exactly zero while every wall particle has   */
+/* v = 0, and with v = 0, V = 0 and f = 0 in state n the update leaves wall positions and        */
+/* velocities unchanged.  While that holds, wall-wall pairs can be left out of the candidate     */
+/* lists without changing any stored value.  flag[0] is raised if it does not hold.              */
+struct WallRestArgs {
+    uint32_t n, wall_below;
+    int dim, xsph;
+    const Rec* rec;
+    const double* nv[3];
+    const double* nV[3];
+    const double* nf[3];
+    const uint32_t* id;
+};
+__global__ __launch_bounds__(SPH_BLOCK) void k_walls_at_rest(WallRestArgs a, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= a.n || a.id[i] >= a.wall_below) return;
+    bool rest = true;
+    for (int d = 0; d < a.dim; ++d) {
+        rest = rest && a.rec[i].xv[d][1] == 0.0 && a.nv[d][i] == 0.0 && a.nf[d][i] == 0.0;
+        if (a.xsph) rest = rest && a.nV[d][i] == 0.0;
+    }
+    if (!rest) flag[0] = 1u;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* candidate lists: every j != i with |xi-xj|^2 <= rl2 at build time, in cell-range order     */
 /* then ascending j.  One row of `stride` entries per particle: entry k of particle i sits at  */
 /* nbr[i*stride + k], so the rounds of the pair loop walk along cache lines they have already  */
@@ -347,9 +375,12 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
                                                           const uint32_t* __restrict__ cbeg,
                                                           const uint32_t* __restrict__ cend, double rl2,
                                                           uint32_t* __restrict__ nbr, uint32_t stride, uint32_t cap,
-                                                          uint32_t* __restrict__ cnt, uint32_t* __restrict__ need) {
+                                                          uint32_t* __restrict__ cnt, uint32_t* __restrict__ need,
+                                                          const uint32_t* __restrict__ id, uint32_t wall_below) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= n) return;
+    /* wall_below > 0: pairs of two wall particles are left out (see k_walls_at_rest) */
+    const bool i_wall = id[i] < wall_below;
     const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
     const int cx = cell_coord(xi, g.lo[0], g.inv[0], g.n[0]);
     const int cy = cell_coord(yi, g.lo[1], g.inv[1], g.n[1]);
@@ -368,6 +399,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
                 const uint32_t b = cbeg[c], e = cend[c]; /* empty cell: b = 0xFFFFFFFF, e = 0 */
                 for (uint32_t j = b; j < e; ++j) {
                     if (j == i) continue;
+                    if (i_wall && id[j] < wall_below) continue;
                     const double dx_ = xi - rec[j].xv[0][0], dy_ = yi - rec[j].xv[1][0];
                     const double dz_ = DIM == 3 ? zi - rec[j].xv[2][0] : 0.0;
                     const double d2 = dist2_exact(dx_, dy_, dz_);
