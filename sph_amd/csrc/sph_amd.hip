@@ -506,7 +506,7 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS), dim3(SPH_BLOCK), 0, c->stream, c->part, c->npairblocks,
                                PART_FIELDS, c->part2);
             hipLaunchKernelGGL(k_sweep_finalize, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->part2, k,
-                               (last && !partial) ? 1 : (last ? 2 : 0));
+                               (last && !partial) ? 1 : (last ? 2 : 0), mode < 2 ? 1 : 0);
             cur = nxt;
         }
         if (!partial) {

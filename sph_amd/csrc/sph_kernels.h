@@ -837,7 +837,8 @@ __global__ void k_step_begin(DevScalars* S) { S->violation = 0; }
 
 /* End of sweep k: errsum, logbase, the travel bound that guards the candidate lists, and
  * after the last sweep the new time step (WCXSPH3D.cpp:280-288, 293-298). */
-__global__ void k_sweep_finalize(DevParams P, DevScalars* S, const double* __restrict__ part2, int k, int last) {
+__global__ void k_sweep_finalize(DevParams P, DevScalars* S, const double* __restrict__ part2, int k, int last,
+                                 int guard_lists) {
     const double maxmu = fold_groups(part2, 0);
     const double maxf2 = fold_groups(part2, 1);
     const double move2 = fold_groups(part2, 2);
@@ -849,7 +850,7 @@ __global__ void k_sweep_finalize(DevParams P, DevScalars* S, const double* __res
     S->disp += sqrt(move2);
     /* the positions just written feed the next sweep's pair loop through lists built earlier:
      * they are only complete while no particle has travelled more than half the skin */
-    if (!last && !(S->disp <= S->disp_limit)) S->violation = 1;
+    if (guard_lists && !last && !(S->disp <= S->disp_limit)) S->violation = 1;
     if (last) {
         const double maxf = sqrt(maxf2);
         S->maxf = maxf;

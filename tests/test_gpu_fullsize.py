@@ -1,0 +1,104 @@
+"""GPU tests at the benchmark's full size (3-D dam break, ~12.7 M particles), where the CPU
+oracle is too slow: size-independent properties and known answers.
+
+  * t=0 Forces: with v = 0, p = 0, rho = rho0 every pair term vanishes, so f = g exactly on the
+    fluid, Rrho = 0, V = 0, maxmu = 0 (WCXSPH3D.cpp:456-458);
+  * first sweep: v+ = 0.5*dt*(g+g), x+ = x + c1*g + c2*g on the fluid, walls unmoved, rho+ =
+    rho0, p+ = 0 (WCXSPH3D.cpp:271-277), bit for bit;
+  * neighbour sets do not depend on the implementation's knobs (brick size, skin, list
+    capacity): per-particle counts equal, the ordered-pair total is n + 2*(unordered pairs);
+  * two runs with different knobs (different summation order) agree to 1e-10 after 2 steps.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from sph_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def dam_break(nx=640, ny=320, nz=48):
+    pstep = 0.1
+    box = (2 * nx * pstep + 0.3, ny * pstep + 0.3, 2 * nz * pstep)
+    return capi.make_case(capi.PROGRAM_WCXSPH3D, (nx, ny, nz), pstep, box, (0.15, 0.15, 0.15))
+
+
+@pytest.fixture(scope="module")
+def big():
+    sim = capi.Sim.from_case(dam_break())
+    yield sim
+    sim.close()
+
+
+def test_fullsize_t0_and_first_sweep(big):
+    sim = big
+    nb = sim.bound_parts
+    x0 = sim.download(capi.STATE_N, names=("x",))["x"]
+    sim.forces(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    st = sim.download(capi.STATE_N, names=("f", "V", "Rrho"))
+    assert not st["f"][:, :nb].any()
+    assert not st["f"][:2, nb:].any() and np.all(st["f"][2, nb:] == -9.81)
+    assert not st["Rrho"].any() and not st["V"].any()
+    assert sim.scalars()["maxmu"] == 0.0
+
+    sc = sim.sweeps(1)
+    st = sim.download(capi.STATE_NP1, names=("x", "v", "rho", "p"))
+    dt, g = 0.0002, -9.81
+    beta = np.float32(0.25)
+    c1 = 0.5 * (dt * dt) * float(np.float32(1) - np.float32(2) * beta)
+    c2 = dt * dt * float(beta)
+    assert np.all(st["v"][2, nb:] == 0.0 + 0.5 * dt * (g + g))
+    assert not st["v"][:2].any() and not st["v"][:, :nb].any()
+    assert np.all(st["x"][2, nb:] == x0[2, nb:] + dt * 0.0 + c1 * g + c2 * g)
+    assert np.array_equal(st["x"][:2], x0[:2]) and np.array_equal(st["x"][:, :nb], x0[:, :nb])
+    assert np.all(st["rho"] == np.float32(1000.0)) and not st["p"].any()
+    # sum over the fluid of |x+ - x|^2; each term is d^2 up to the rounding of (x + d) - x
+    d = (c1 * g + c2 * g)
+    n_fluid = sim.npts - nb
+    assert abs(sc["errsum"] - n_fluid * d * d) <= 1e-6 * n_fluid * d * d
+
+
+def test_fullsize_neighbour_counts_do_not_depend_on_knobs(big):
+    offs = np.zeros(big.npts + 1, np.uint64)
+    big._chk(capi.lib().sph_neighbours(big._h, capi.STATE_N, offs.ctypes.data, None), "sph_neighbours")
+    total = int(offs[-1])
+    assert (total - big.npts) % 2 == 0  # every unordered pair appears in two rows
+    counts = np.diff(offs.astype(np.int64))
+    assert counts.min() >= 1
+    assert 27 in counts[big.bound_parts:]  # interior lattice stencil incl. the particle itself
+
+    os.environ["SPH_BRICK_LOG2"] = "1"
+    try:
+        other = capi.Sim.from_case(dam_break(), skin_frac=0.03, max_neighbours=48)
+    finally:
+        del os.environ["SPH_BRICK_LOG2"]
+    offs2 = np.zeros(other.npts + 1, np.uint64)
+    other._chk(capi.lib().sph_neighbours(other._h, capi.STATE_N, offs2.ctypes.data, None), "sph_neighbours")
+    assert np.array_equal(offs, offs2)
+
+    # two steps with different cell order, skin and list capacity: same physics to rounding
+    for s in (big, other):
+        s.forces(capi.STATE_N)
+        s.zero_boundary_forces(capi.STATE_N)
+    # fresh state for `big` (the previous test left it inside a step)
+    p, st = capi.case_init(dam_break())
+    big.upload(capi.STATE_N, st)
+    big.upload(capi.STATE_NP1, st)
+    big.set_dt(0.0002)
+    big.forces(capi.STATE_N)
+    big.zero_boundary_forces(capi.STATE_N)
+    a = big.step(2)
+    b = other.step(2)
+    assert abs(a["dt"] - b["dt"]) <= 1e-12 * a["dt"]
+    assert a["hit_pairs"] == b["hit_pairs"]
+    ga = big.download(capi.STATE_NP1, names=("x", "v", "f", "rho"))
+    gb = other.download(capi.STATE_NP1, names=("x", "v", "f", "rho"))
+    for k in ("x", "v", "f"):
+        assert np.isfinite(ga[k]).all()
+        scale = np.max(np.abs(ga[k]))
+        assert np.max(np.abs(ga[k] - gb[k])) <= 1e-10 * scale, k
+    assert np.max(np.abs(ga["rho"].astype(np.float64) - gb["rho"])) <= 2e-4  # a few float ulp of 1000
+    other.close()

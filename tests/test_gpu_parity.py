@@ -1,0 +1,284 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bars (stated once, used throughout):
+  * neighbour sets: bit-exact (CSR offsets and columns equal);
+  * double fields x, v, V, f: max|a-b| <= 1e-10 * max|b| per field, for one Forces call or one
+    sweep from identical inputs; the same bound is asserted after 10 full steps on the small
+    cases (measured drift is ~1e-15) and the measured drift is printed;
+  * float fields rho, p: equal, or 1 float ulp apart where the double value lands on a
+    rounding tie; Rrho (a float store of a cancelling sum): |a-b| <= 1e-6 * max|b|;
+  * scalars dt, maxmu, maxf: relative 1e-12; errsum/logbase (order-dependent sums in the
+    reference, diagnostics only): relative 1e-9.
+The oracle itself is unpinned by the reference (it ships no fixtures); see oracle/sph_oracle.h.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from sph_amd import capi
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-10
+CASES = util.small_cases()
+
+
+def start(spec, **overrides):
+    """main() up to the time loop: InitSPH, copy, Forces at t=0, wall f zeroed -- on both sides."""
+    oc, pc = util.both_cases(spec)
+    orc = O.Oracle(oc)
+    sim = capi.Sim.from_case(pc, **overrides)
+    orc.forces(O.STATE_N)
+    orc.zero_boundary_f(O.STATE_N)
+    sim.forces(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    return orc, sim
+
+
+def assert_state_close(g, o, what, tol=TOL, ulp=1):
+    for k in ("x", "v", "V", "f"):
+        err = util.rel_err(g[k].T, o[k])
+        assert err <= tol, "%s: field %s off by %.3e" % (what, k, err)
+    for k in ("rho", "p"):
+        u = util.float_ulp_diff(g[k], o[k])
+        assert u.max() <= ulp, "%s: %s differs by %d float ulp" % (what, k, u.max())
+    s = max(float(np.max(np.abs(o["Rrho"]))), 1e-30)
+    assert float(np.max(np.abs(g["Rrho"].astype(np.float64) - o["Rrho"]))) <= 1e-6 * s, what + ": Rrho"
+
+
+def assert_scalars_close(sc, osc, what):
+    for k in ("dt", "maxmu", "maxf"):
+        assert abs(sc[k] - osc[k]) <= 1e-12 * max(abs(osc[k]), 1e-300), "%s: %s %r vs %r" % (what, k, sc[k], osc[k])
+    assert abs(sc["errsum"] - osc["errsum"]) <= 1e-9 * max(abs(osc["errsum"]), 1e-300), what
+    assert abs(sc["logbase"] - osc["logbase"]) <= 1e-9 * max(abs(osc["logbase"]), 1.0), what
+    assert np.float32(sc["t"]) == np.float32(osc["t"]) or abs(sc["t"] - osc["t"]) <= 1e-6 * abs(osc["t"]), what
+
+
+# ---- neighbour sets ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_neighbour_sets_exact_at_t0(name):
+    oc, pc = util.both_cases(CASES[name])
+    orc, sim = O.Oracle(oc), capi.Sim.from_case(pc)
+    for gw, ow in ((capi.STATE_N, O.STATE_N), (capi.STATE_NP1, O.STATE_NP1)):
+        go, gc = sim.neighbours(gw)
+        oo, occ = orc.neighbours(ow)
+        assert np.array_equal(go, oo) and np.array_equal(gc, occ)
+    sim.close()
+
+
+@pytest.mark.parametrize("name", ["wcxsph_default", "wcxsph3d_default", "wcsph_fine"])
+def test_neighbour_sets_exact_on_jittered_positions(name):
+    # jitter moves lattice pairs that sit exactly on the search radius to either side of it
+    oc, pc = util.both_cases(CASES[name])
+    orc, sim = O.Oracle(oc), capi.Sim.from_case(pc)
+    for seed in (12345, 7):
+        x = util.jitter(orc.get_state(O.STATE_N)["x"], oc.pstep, seed=seed)
+        orc.set_state(O.STATE_NP1, x=x)
+        sim.upload(capi.STATE_NP1, {"x": np.ascontiguousarray(x.T)})
+        go, gc = sim.neighbours(capi.STATE_NP1)
+        oo, occ = orc.neighbours(O.STATE_NP1, O.SEARCH_BRUTE)
+        assert np.array_equal(go, oo) and np.array_equal(gc, occ)
+    sim.close()
+
+
+@pytest.mark.parametrize("name", ["wcxsph_default", "wcxsph3d_block"])
+def test_neighbour_sets_exact_at_every_sweep(name):
+    # the sets Forces sees at the start of each of the 8 sweeps of a step, from identical inputs
+    orc, sim = start(CASES[name])
+    orc.step(3)
+    sim.step(3)
+    base = orc.get_state(O.STATE_NP1)
+    basen = orc.get_state(O.STATE_N)
+    for k in range(1, 8):
+        o2 = O.Oracle(util.both_cases(CASES[name])[0])
+        o2.set_state(O.STATE_N, **basen)
+        o2.set_state(O.STATE_NP1, **base)
+        o2.set_dt(orc.scalars()["dt"])
+        o2.step(1, k)
+        st = o2.get_state(O.STATE_NP1)
+        sim.upload(capi.STATE_NP1, {"x": np.ascontiguousarray(st["x"].T)})
+        go, gc = sim.neighbours(capi.STATE_NP1)
+        oo, occ = o2.neighbours(O.STATE_NP1)
+        assert np.array_equal(go, oo) and np.array_equal(gc, occ), "sweep %d" % k
+    sim.close()
+
+
+# ---- Forces and single sweeps from identical inputs --------------------------------------------
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forces_at_t0(name):
+    orc, sim = start(CASES[name])
+    assert_state_close(sim.download(capi.STATE_N), orc.get_state(O.STATE_N), name)
+    assert sim.scalars()["maxmu"] == orc.scalars()["maxmu"] == 0.0
+    sim.close()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forces_on_a_moving_state(name):
+    # Forces() alone on a state taken from the middle of a run
+    orc, sim = start(CASES[name])
+    orc.step(5)
+    st = orc.get_state(O.STATE_NP1)
+    sim.upload(capi.STATE_NP1, util.to_component_major(st))
+    orc.forces(O.STATE_NP1)
+    sim.forces(capi.STATE_NP1)
+    assert_state_close(sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1), name)
+    assert abs(sim.scalars()["maxmu"] - orc.scalars()["maxmu"]) <= 1e-12 * max(orc.scalars()["maxmu"], 1e-300)
+    sim.close()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("nsweeps", [1, 2, 8])
+def test_sweeps_from_identical_inputs(name, nsweeps):
+    orc, sim = start(CASES[name])
+    orc.step(4)
+    # hand the oracle's exact states to the GPU, then run the same number of sweeps on both
+    sim.upload(capi.STATE_N, util.to_component_major(orc.get_state(O.STATE_N)))
+    sim.upload(capi.STATE_NP1, util.to_component_major(orc.get_state(O.STATE_NP1)))
+    sim.set_dt(orc.scalars()["dt"])
+    orc.step(1, nsweeps)
+    sc = sim.sweeps(nsweeps)
+    assert_state_close(sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1), "%s/%d" % (name, nsweeps))
+    osc = orc.scalars()
+    assert abs(sc["maxmu"] - osc["maxmu"]) <= 1e-12 * max(osc["maxmu"], 1e-300)
+    assert abs(sc["errsum"] - osc["errsum"]) <= 1e-9 * max(osc["errsum"], 1e-300)
+    sim.close()
+
+
+# ---- whole steps, drift ------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_ten_steps_and_drift(name):
+    orc, sim = start(CASES[name])
+    worst = 0.0
+    for step in range(10):
+        orc.step(1)
+        sc = sim.step(1)
+        assert_scalars_close(sc, orc.scalars(), "%s step %d" % (name, step))
+        g, o = sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1)
+        worst = max(worst, max(util.rel_err(g[k].T, o[k]) for k in ("x", "v", "V", "f")))
+    print("\n%s: drift after 10 steps, worst field-relative error %.3e" % (name, worst))
+    for gw, ow in ((capi.STATE_N, O.STATE_N), (capi.STATE_NP1, O.STATE_NP1)):
+        assert_state_close(sim.download(gw), orc.get_state(ow), name)
+    go, gc = sim.neighbours(capi.STATE_NP1)
+    oo, occ = orc.neighbours(O.STATE_NP1)
+    assert np.array_equal(go, oo) and np.array_equal(gc, occ)
+    assert sc["step_redos"] == 0
+    sim.close()
+
+
+@pytest.mark.parametrize("name,variant", [("wcsph", 0), ("wcxsph", 1), ("wcxsph3d", 2)])
+def test_against_golden_vectors(name, variant):
+    gold = np.load(os.path.join(GOLDEN, "%s_default_3steps.npz" % name))
+    sim = capi.Sim.from_case(capi.default_case(variant))
+    sim.forces(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    sc = sim.step(int(gold["steps"]))
+    g = sim.download(capi.STATE_NP1)
+    assert_state_close(g, {k: gold[k] for k in ("x", "v", "V", "f", "rho", "p", "Rrho")}, name)
+    assert_scalars_close(sc, {k: float(gold[k]) for k in ("dt", "t", "maxmu", "maxf", "errsum", "logbase")}, name)
+    go, gc = sim.neighbours(capi.STATE_NP1)
+    assert np.array_equal(go, gold["nbr_offsets"]) and np.array_equal(gc, gold["nbr_cols"])
+    sim.close()
+
+
+# ---- knobs must not change results ---------------------------------------------------------------
+
+def test_tight_skin_forces_rebuilds_and_redos_but_same_answer():
+    # a skin this thin is outrun inside a step: the step is redone with fresh lists
+    name = "wcxsph3d_block"
+    orc, sim = start(CASES[name], skin_frac=1e-4)
+    orc.step(6)
+    sc = sim.step(6)
+    assert sc["list_rebuilds"] >= 6
+    assert_state_close(sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1), name)
+    assert_scalars_close(sc, orc.scalars(), name)
+    sim.close()
+
+
+def test_small_list_capacity_grows():
+    name = "wcxsph3d_default"
+    orc, sim = start(CASES[name], max_neighbours=8)
+    orc.step(2)
+    sc = sim.step(2)
+    assert_state_close(sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1), name)
+    sim.close()
+
+
+def test_moving_walls_keep_wall_wall_pairs():
+    # wall particles that move void the shortcut that leaves wall-wall pairs out of the lists
+    name = "wcxsph_default"
+    oc, pc = util.both_cases(CASES[name])
+    orc, sim = O.Oracle(oc), capi.Sim.from_case(pc)
+    st = orc.get_state(O.STATE_N)
+    st["v"][:orc.bound_parts, 0] = 0.3
+    for w in (O.STATE_N, O.STATE_NP1):
+        orc.set_state(w, v=st["v"])
+    for w in (capi.STATE_N, capi.STATE_NP1):
+        sim.upload(w, {"v": np.ascontiguousarray(st["v"].T)})
+    orc.forces(O.STATE_N); orc.zero_boundary_f(O.STATE_N)
+    sim.forces(capi.STATE_N); sim.zero_boundary_forces(capi.STATE_N)
+    orc.step(3)
+    sim.step(3)
+    assert_state_close(sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1), name)
+    sim.close()
+
+
+# ---- API behaviour -------------------------------------------------------------------------------
+
+def test_upload_download_round_trip_and_errors():
+    p, st = capi.case_init(capi.default_case(1))
+    sim = capi.Sim(p)
+    with pytest.raises(capi.SphError):
+        sim.step(1)  # nothing uploaded yet
+    rng = np.random.default_rng(3)
+    for k in ("v", "f", "V"):
+        st[k][:] = rng.normal(size=st[k].shape)
+    st["p"][:] = rng.normal(size=st["p"].shape).astype(np.float32)
+    for w in (capi.STATE_N, capi.STATE_NP1):
+        sim.upload(w, st)
+        back = sim.download(w)
+        for k in st:
+            assert np.array_equal(back[k], st[k]), (w, k)
+    # after a rebuild (cell order changes) the original order is still what comes back
+    sim.neighbours(capi.STATE_NP1)
+    back = sim.download(capi.STATE_NP1)
+    for k in st:
+        assert np.array_equal(back[k], st[k]), k
+    sim.close()
+    bad = capi.Params.from_buffer_copy(p)
+    bad.dim = 4
+    with pytest.raises(capi.SphError):
+        capi.Sim(bad)
+
+
+# ---- larger cases --------------------------------------------------------------------------------
+
+def test_medium_2d_wcsph_one_step():
+    # config 2 physics (single mass, no XSPH, wall spacing 0.7 r0) at ~50k particles
+    spec = dict(program=0, npart=(180, 260), pstep=0.01, box=(4.0, 3.0), start=(0.03, 0.03), dt0=2e-5)
+    orc, sim = start(spec)
+    orc.step(1)
+    sc = sim.step(1)
+    assert_state_close(sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1), "wcsph 50k")
+    assert_scalars_close(sc, orc.scalars(), "wcsph 50k")
+    sim.close()
+
+
+def test_medium_3d_one_step():
+    spec = dict(program=2, npart=(40, 30, 24), pstep=0.1, box=(8.3, 3.3, 4.8), start=(0.15, 0.15, 0.15))
+    orc, sim = start(spec)
+    orc.step(1)
+    sc = sim.step(1)
+    assert_state_close(sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1), "3d 65k")
+    assert_scalars_close(sc, orc.scalars(), "3d 65k")
+    go = sim.neighbours(capi.STATE_NP1)
+    oo = orc.neighbours(O.STATE_NP1)
+    assert np.array_equal(go[0], oo[0]) and np.array_equal(go[1], oo[1])
+    sim.close()
