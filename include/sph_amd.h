@@ -148,6 +148,9 @@ typedef struct sph_case {
     double  box[3];      /* Box */
     double  start[3];    /* Start */
     double  dt0;         /* initial dt */
+    /* Settings-file overrides of constants the reference fixes at compile time; 0 keeps the
+     * reference's value (rho0 1000, Cs 50, alpha 0.025, gravity 9.81). */
+    double  rho0, Cs, alpha, gravity;
 } sph_case;
 
 /* The constants as shipped in the given reference program. */

@@ -55,7 +55,8 @@ class Scalars(C.Structure):
 
 class Case(C.Structure):
     _fields_ = [("program", C.c_int32), ("npart", C.c_int32 * 3), ("pstep", C.c_double),
-                ("box", C.c_double * 3), ("start", C.c_double * 3), ("dt0", C.c_double)]
+                ("box", C.c_double * 3), ("start", C.c_double * 3), ("dt0", C.c_double),
+                ("rho0", C.c_double), ("Cs", C.c_double), ("alpha", C.c_double), ("gravity", C.c_double)]
 
 
 class SphError(RuntimeError):

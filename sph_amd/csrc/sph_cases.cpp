@@ -135,7 +135,7 @@ int sph_case_params(const sph_case* c, sph_params* p, double* simmass_out, doubl
         const double finish = c->start[d] + c->pstep * c->npart[d] * 1.0; /* Finish, WCXSPH3D.cpp:48 */
         extent[d] = finish - c->start[d];
     }
-    const double rho0 = 1000.0;
+    const double rho0 = c->rho0 > 0 ? c->rho0 : 1000.0;
     double volume = extent[0] * extent[1];
     if (dim == 3) volume = volume * extent[2];
     /* Simmass / Boundmass (WCXSPH3D.cpp:52-53, WCXSPH.cpp:49-50), mass (WCSPH.cpp:55) */
@@ -144,7 +144,7 @@ int sph_case_params(const sph_case* c, sph_params* p, double* simmass_out, doubl
     double boundmass = simmass;
     if (c->program == SPH_PROGRAM_WCXSPH) boundmass = 0.9 * rho0 * per_particle;
     if (c->program == SPH_PROGRAM_WCXSPH3D) boundmass = 1.0 * rho0 * per_particle;
-    const double Cs = 50, gam = 7.0;
+    const double Cs = c->Cs > 0 ? c->Cs : 50, gam = 7.0;
     p->dim = dim;
     p->variant = c->program == SPH_PROGRAM_WCSPH ? SPH_VARIANT_WCSPH : SPH_VARIANT_WCXSPH;
     p->bound_parts = wall_count(c);
@@ -165,9 +165,9 @@ int sph_case_params(const sph_case* c, sph_params* p, double* simmass_out, doubl
     p->Cs = Cs;
     p->gam = gam;
     p->B = rho0 * pow(Cs, 2) / gam; /* WCXSPH3D.cpp:56 */
-    p->alpha = 0.025;               /* WCXSPH3D.cpp:142 */
+    p->alpha = c->alpha > 0 ? c->alpha : 0.025; /* WCXSPH3D.cpp:142 */
     p->eps = 0.2;                   /* WCXSPH3D.cpp:143 */
-    p->g = -9.81;
+    p->g = c->gravity > 0 ? -c->gravity : -9.81;
     p->g_axis = dim - 1;            /* WCXSPH3D.cpp:195, WCXSPH.cpp:191 */
     p->subits = 8;
     const float beta = 0.25;        /* a float in the reference, WCXSPH3D.cpp:72 */

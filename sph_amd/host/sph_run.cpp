@@ -1,0 +1,264 @@
+/*
+ * sph_run -- the reference's time-stepping driver on top of the C ABI (include/sph_amd.h).
+ *
+ * Keeps what main() of the reference does around the hot path (WCXSPH3D.cpp:439-499,
+ * WCXSPH.cpp:411-471, WCSPH.cpp:412-474): InitSPH, the t=0 Forces call, the settings summary,
+ * the Tecplot .plt strand file, the per-frame convergence line and the wall-clock print.
+ * The reference takes a settings file name on its command line and ignores it
+ * (makefile:15-19, Sample_Input.txt); here it is read.
+ *
+ * Settings grammar (Sample_Input.txt:1-12): one "key value" per line, '#' starts a comment.
+ *   default_params? yes|no   yes: ignore every other physics key, run the program as shipped
+ *   outfile NAME             NAME.plt and NAME_Settings.txt          (reference: Test)
+ *   nframes N                Nframe                                  (reference: 2000)
+ *   npframe N                Ndtframe                                (reference: 10)
+ *   dt X                     initial time step                       (reference: 0.0002)
+ *   psize X                  Pstep                                   (reference: 0.1)
+ *   rho_ref X                rho0                                    (reference: 1000)
+ *   viscosity X              artificial-viscosity alpha              (reference: 0.025)
+ *   gravity X                gravitational strength                  (reference: 9.81)
+ *   Bulk_mod X               no counterpart: the reference derives the Tait modulus from the
+ *                            speed of sound (B = rho0*Cs^2/gam, WCXSPH3D.cpp:54-56); accepted
+ *                            and ignored with a notice
+ *   simtype Box              the only initialiser the reference has
+ * Extensions of this driver:
+ *   program WCSPH|WCXSPH|WCXSPH3D   which reference program to run  (default WCXSPH)
+ *   npart NX NY [NZ], box BX BY [BZ], start SX SY [SZ], cs X
+ *   reinit 0|1               per-frame DensityReinit                (default 1)
+ *   device N                 HIP device ordinal
+ */
+#include "../../include/sph_amd.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Settings {
+    bool defaults = true;
+    std::string outfile = "Test";
+    int nframes = 2000, npframe = 10;
+    int program = SPH_PROGRAM_WCXSPH;
+    int reinit = 1, device = -1;
+    bool have_npart = false, have_box = false, have_start = false;
+    double dt = 0, psize = 0, rho_ref = 0, viscosity = 0, gravity = 0, cs = 0;
+    double npart[3] = {0, 0, 0}, box[3] = {0, 0, 0}, start[3] = {0, 0, 0};
+};
+
+bool read_settings(const char* path, Settings& s) {
+    std::ifstream in(path);
+    if (!in.is_open()) return false;
+    std::string line;
+    while (std::getline(in, line)) {
+        const size_t hash = line.find('#');
+        if (hash != std::string::npos) line.erase(hash);
+        std::istringstream ls(line);
+        std::string key;
+        if (!(ls >> key)) continue;
+        if (key == "default_params?") { std::string v; ls >> v; s.defaults = (v == "yes" || v == "Yes" || v == "1"); }
+        else if (key == "outfile") ls >> s.outfile;
+        else if (key == "nframes") ls >> s.nframes;
+        else if (key == "npframe") ls >> s.npframe;
+        else if (key == "dt") ls >> s.dt;
+        else if (key == "psize") ls >> s.psize;
+        else if (key == "rho_ref") ls >> s.rho_ref;
+        else if (key == "viscosity") ls >> s.viscosity;
+        else if (key == "gravity") ls >> s.gravity;
+        else if (key == "cs") ls >> s.cs;
+        else if (key == "Bulk_mod") std::cout << "Note: Bulk_mod has no counterpart (B follows from the speed of sound); ignored." << std::endl;
+        else if (key == "simtype") { std::string v; ls >> v; if (v != "Box") { std::cerr << "Unknown simtype " << v << std::endl; return false; } }
+        else if (key == "program") {
+            std::string v; ls >> v;
+            if (v == "WCSPH") s.program = SPH_PROGRAM_WCSPH;
+            else if (v == "WCXSPH") s.program = SPH_PROGRAM_WCXSPH;
+            else if (v == "WCXSPH3D") s.program = SPH_PROGRAM_WCXSPH3D;
+            else { std::cerr << "Unknown program " << v << std::endl; return false; }
+        }
+        else if (key == "npart") { s.have_npart = true; for (int d = 0; d < 3 && (ls >> s.npart[d]); ++d) {} }
+        else if (key == "box") { s.have_box = true; for (int d = 0; d < 3 && (ls >> s.box[d]); ++d) {} }
+        else if (key == "start") { s.have_start = true; for (int d = 0; d < 3 && (ls >> s.start[d]); ++d) {} }
+        else if (key == "reinit") ls >> s.reinit;
+        else if (key == "device") ls >> s.device;
+        else std::cout << "Note: unknown settings key '" << key << "' ignored." << std::endl;
+    }
+    return true;
+}
+
+struct HostState {
+    int dim = 0;
+    size_t n = 0;
+    std::vector<double> x[3], v[3], V[3], f[3];
+    std::vector<float> rho, p, Rrho, m;
+    sph_fields fields() {
+        sph_fields h = {};
+        for (int d = 0; d < dim; ++d) { h.x[d] = x[d].data(); h.v[d] = v[d].data(); h.V[d] = V[d].data(); h.f[d] = f[d].data(); }
+        h.rho = rho.data(); h.p = p.data(); h.Rrho = Rrho.data(); h.m = m.data();
+        return h;
+    }
+    void resize(int dim_, size_t n_) {
+        dim = dim_; n = n_;
+        for (int d = 0; d < dim; ++d) { x[d].assign(n, 0); v[d].assign(n, 0); V[d].assign(n, 0); f[d].assign(n, 0); }
+        rho.assign(n, 0); p.assign(n, 0); Rrho.assign(n, 0); m.assign(n, 0);
+    }
+    double norm(const std::vector<double>* a, size_t i) const {
+        double s = a[0][i] * a[0][i] + a[1][i] * a[1][i];
+        if (dim == 3) s = s + a[2][i] * a[2][i];
+        return sqrt(s);
+    }
+};
+
+/* write_settings (WCXSPH3D.cpp:381-406): same lines, same default stream precision */
+void write_settings(const std::string& name, int nframes, int npframe, double dt, double pstep, double mass, double rho0,
+                    double H, double gravity, uint64_t bound_parts, uint64_t simpts) {
+    std::ofstream fp(name.c_str(), std::ios::out);
+    if (fp.is_open()) {
+        fp << "SIMULATION PARAMETERS:" << std::endl;
+        fp << "\tNumber of frames (" << nframes << ")" << std::endl;
+        fp << "\tSteps per frame (" << npframe << ")" << std::endl;
+        fp << "\tTime step (" << dt << ")" << std::endl;
+        fp << "\tParticle Spacing (" << pstep << ")" << std::endl;
+        fp << "\tParticle Mass (" << mass << ")" << std::endl;
+        fp << "\tReference density (" << rho0 << ")" << std::endl;
+        fp << "\tSupport Radius (" << H << ")" << std::endl;
+        fp << "\tGravitational strength (" << gravity << ")" << std::endl;
+        fp << "\tNumber of boundary points (" << bound_parts << ")" << std::endl;
+        fp << "\tNumber of simulation points (" << simpts << ")" << std::endl;
+        fp << "\tIntegrator type (Newmark_Beta)" << std::endl;
+        fp.close();
+    } else {
+        std::cout << "Error opening the output file." << std::endl;
+        exit(-1);
+    }
+}
+
+/* write_frame_data (WCXSPH3D.cpp:408-437; WCSPH.cpp:378-410 adds DATAPACKING=POINT and prints
+ * the components in its NaN report) */
+void write_frame(HostState& s, std::ofstream& fp, float t, uint64_t bound_parts, int program) {
+    auto row = [&](std::ostream& o, size_t i) {
+        for (int d = 0; d < s.dim; ++d) o << s.x[d][i] << " ";
+        o << s.norm(s.v, i) << " ";
+        o << s.norm(s.f, i) << " ";
+        o << s.rho[i] << " " << s.p[i] << std::endl;
+    };
+    fp << "ZONE t=\"Boundary Data\", STRANDID=1, SOLUTIONTIME=" << t << std::endl;
+    for (size_t i = 0; i < bound_parts; ++i) row(fp, i);
+    fp << "ZONE t=\"Particle Data\", STRANDID=2, SOLUTIONTIME=" << t;
+    if (program == SPH_PROGRAM_WCSPH) fp << ", DATAPACKING=POINT";
+    fp << std::endl;
+    for (size_t i = bound_parts; i < s.n; ++i) {
+        bool bad = false;
+        for (int d = 0; d < s.dim; ++d) bad = bad || s.x[d][i] != s.x[d][i] || s.v[d][i] != s.v[d][i] || s.f[d][i] != s.f[d][i];
+        if (bad) {
+            std::cerr << std::endl << "Simulation is broken. A value is nan." << std::endl;
+            std::cerr << "Broken line..." << std::endl;
+            if (program == SPH_PROGRAM_WCSPH) {
+                for (int d = 0; d < s.dim; ++d) std::cerr << s.x[d][i] << " ";
+                for (int d = 0; d < s.dim; ++d) std::cerr << s.v[d][i] << " ";
+                for (int d = 0; d < s.dim; ++d) std::cerr << s.f[d][i] << " ";
+                std::cerr << s.rho[i] << " " << s.p[i] << std::endl;
+            } else {
+                row(std::cerr, i);
+            }
+            fp.close();
+            exit(-1);
+        }
+        row(fp, i);
+    }
+}
+
+void die(sph_ctx* ctx, const char* what) {
+    std::cerr << what << ": " << sph_last_error(ctx) << std::endl;
+    exit(-1);
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+    auto t1 = std::chrono::high_resolution_clock::now();
+    Settings st;
+    if (argc > 1 && !read_settings(argv[1], st)) {
+        std::cerr << "Error opening the settings file." << std::endl;
+        exit(-1);
+    }
+
+    sph_case cs;
+    if (sph_case_default(st.program, &cs) != SPH_OK) exit(-1);
+    if (!st.defaults) {
+        if (st.dt > 0) cs.dt0 = st.dt;
+        if (st.psize > 0) cs.pstep = st.psize;
+        cs.rho0 = st.rho_ref;
+        cs.alpha = st.viscosity;
+        cs.gravity = st.gravity;
+        cs.Cs = st.cs;
+        for (int d = 0; d < 3; ++d) {
+            if (st.have_npart && st.npart[d] > 0) cs.npart[d] = (int)st.npart[d];
+            if (st.have_box && st.box[d] > 0) cs.box[d] = st.box[d];
+            if (st.have_start) cs.start[d] = st.start[d];
+        }
+    }
+    sph_params prm;
+    double simmass = 0, boundmass = 0;
+    if (sph_case_params(&cs, &prm, &simmass, &boundmass) != SPH_OK) {
+        std::cerr << "Invalid simulation definition." << std::endl;
+        exit(-1);
+    }
+    prm.device = st.device;
+    const uint64_t simpts = prm.npts - prm.bound_parts;
+
+    /* InitSPH (WCXSPH3D.cpp:306-379) */
+    std::cout << "Initialising simulation with " << simpts << " particles" << std::endl;
+    HostState hs;
+    hs.resize(prm.dim, (size_t)prm.npts);
+    sph_fields h = hs.fields();
+    if (sph_case_init(&cs, &h) != SPH_OK) exit(-1);
+    std::cout << "Total Particles: " << prm.npts << std::endl;
+
+    sph_ctx* ctx = nullptr;
+    if (sph_create(&prm, &ctx) != SPH_OK) die(ctx, "sph_create");
+    if (sph_upload(ctx, SPH_STATE_N, &h) != SPH_OK) die(ctx, "sph_upload");
+    if (sph_upload(ctx, SPH_STATE_NP1, &h) != SPH_OK) die(ctx, "sph_upload"); /* the particlesh copy, :450-451 */
+
+    if (sph_forces(ctx, SPH_STATE_N) != SPH_OK) die(ctx, "sph_forces");       /* :456 */
+    if (sph_zero_boundary_forces(ctx, SPH_STATE_N) != SPH_OK) die(ctx, "sph_zero_boundary_forces"); /* :457-458 */
+
+    write_settings(st.outfile + "_Settings.txt", st.nframes, st.npframe, cs.dt0, cs.pstep, simmass, prm.rho0, prm.H,
+                   -prm.g, prm.bound_parts, simpts);
+
+    std::ofstream f1((st.outfile + ".plt").c_str(), std::ios::out);
+    if (f1.is_open()) {
+        f1 << std::fixed << std::setprecision(3);
+        std::cout << "Starting simulation..." << std::endl;
+        f1 << (prm.dim == 3 ? "VARIABLES = x, y, z, V, F, rho, P" : "VARIABLES = x, y, V, F, rho, P") << std::endl;
+        if (sph_download(ctx, SPH_STATE_N, &h) != SPH_OK) die(ctx, "sph_download");
+        write_frame(hs, f1, 0.f, prm.bound_parts, st.program);
+
+        sph_scalars sc;
+        if (sph_get_scalars(ctx, &sc) != SPH_OK) die(ctx, "sph_get_scalars");
+        for (int frame = 1; frame <= st.nframes; ++frame) {
+            std::cout << "Frame Number: " << frame << "\tError: " << log10(sqrt(sc.errsum / (1.0 * prm.npts))) - sc.logbase
+                      << std::endl;
+            if (sph_step(ctx, st.npframe, &sc) != SPH_OK) die(ctx, "sph_step");
+            if (st.reinit && sph_density_reinit(ctx) != SPH_OK) die(ctx, "sph_density_reinit");
+            if (sph_download(ctx, SPH_STATE_NP1, &h) != SPH_OK) die(ctx, "sph_download");
+            write_frame(hs, f1, sc.t, prm.bound_parts, st.program);
+        }
+        f1.close();
+    } else {
+        std::cerr << "Error opening frame output file." << std::endl;
+        exit(-1);
+    }
+    sph_destroy(ctx);
+
+    std::cout << "Simulation complete. Output is available in /Output!" << std::endl;
+    auto t2 = std::chrono::high_resolution_clock::now();
+    auto duration = std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count();
+    std::cout << "Time taken:\t" << duration / 1e06 << " seconds" << std::endl;
+    return 0;
+}
