@@ -61,6 +61,15 @@ typedef struct sph_params {
     double   skin_frac;        /* neighbour-candidate skin as a fraction of the search radius */
     int32_t  max_neighbours;   /* initial per-particle candidate capacity (grows on demand) */
     int32_t  device;           /* HIP device ordinal; -1 = current device */
+    /* Slab decomposition along x, one context per GPU (no counterpart in the reference, which
+     * is one process on one core).  nranks <= 1: a single domain, the fields below are unused.
+     * Otherwise npts is the number of particles this rank owns, npts_global the total (the
+     * convergence diagnostic divides by it, WCXSPH3D.cpp:288), capacity the room for owned
+     * plus halo particles, and [slab_lo, slab_hi) the x-interval this rank owns. */
+    int32_t  rank, nranks;
+    uint64_t npts_global;
+    uint64_t capacity;
+    double   slab_lo, slab_hi;
 } sph_params;
 
 /* Caller-owned host arrays in ORIGINAL particle order, one array per component
@@ -138,6 +147,38 @@ int sph_profile_enable(sph_ctx* ctx, int32_t on);
 int sph_profile_read(sph_ctx* ctx, double* pair_ms_total, uint64_t* pair_launches,
                      double* rebuild_ms_total, uint64_t* rebuilds);
 
+/* ---- slab decomposition ----------------------------------------------------------------
+ * No counterpart in the reference.  A rank owns the particles whose x lay in its interval at
+ * upload.  Before every Forces call each rank needs, from each slab neighbour, the records of
+ * the particles within the candidate radius of the shared plane (the halo); per step the
+ * ranks agree on max(mu), max|f|, sum|dx|^2 and on whether the step must be redone.  The
+ * library does the selecting, packing and scheduling; moving bytes between ranks is the
+ * transport's job. */
+typedef struct sph_transport {
+    void* user;
+    /* 1: buffers handed to the callbacks are host memory (the library stages them); 0: device
+     * memory, and `stream` (a hipStream_t) orders the transfer. */
+    int32_t host_buffers;
+    /* Send `nsendL` bytes to the left neighbour (rank-1) and `nsendR` to the right (rank+1);
+     * receive exactly `nrecvL` / `nrecvR` bytes from them.  A side without a neighbour has
+     * byte counts 0.  Returns 0 on success. */
+    int (*sendrecv)(void* user, const void* sendL, uint64_t nsendL, void* recvL, uint64_t nrecvL,
+                    const void* sendR, uint64_t nsendR, void* recvR, uint64_t nrecvR, void* stream);
+    /* In-place all-reduce of n doubles over all ranks; op 0 = max, 1 = sum. */
+    int (*allreduce)(void* user, double* vals, int32_t n, int32_t op, void* stream);
+} sph_transport;
+
+/* Installs the transport (copied).  Required before the first Forces/step when nranks > 1. */
+int sph_set_transport(sph_ctx* ctx, const sph_transport* t);
+/* Global original indices of this rank's particles, in upload order (wall particles are the
+ * ones below bound_parts of the GLOBAL numbering).  Required when nranks > 1. */
+int sph_upload_global_ids(sph_ctx* ctx, const uint32_t* gids);
+/* A transport over RCCL (ncclSend/ncclRecv/ncclAllReduce on the context's device).
+ * `unique_id` is the 128-byte ncclUniqueId, identical on all ranks (rank 0 obtains it with
+ * sph_rccl_unique_id and the launcher broadcasts it). */
+int sph_rccl_unique_id(void* unique_id_128);
+int sph_use_rccl(sph_ctx* ctx, const void* unique_id_128);
+
 /* ---- the reference's case set-up, host side ----------------------------------------- */
 /* The "Simulation Definition" block (WCXSPH3D.cpp:39-48; WCXSPH.cpp:36-45; WCSPH.cpp:42-51). */
 enum { SPH_PROGRAM_WCSPH = 0, SPH_PROGRAM_WCXSPH = 1, SPH_PROGRAM_WCXSPH3D = 2 };
@@ -160,6 +201,14 @@ int sph_case_params(const sph_case* c, sph_params* out, double* simmass, double*
 /* InitSPH (WCXSPH3D.cpp:306-379; WCXSPH.cpp:301-350; WCSPH.cpp:297-350): fills x, v, V, f,
  * rho, p, Rrho, m of `dst` (arrays of params.npts entries; NULL entries skipped). */
 int sph_case_init(const sph_case* c, const sph_fields* dst);
+
+/* The particles of a case whose x lies in [xlo, xhi), in the order of InitSPH, with their
+ * global indices.  Call with dst == NULL to get the count only. */
+int sph_case_init_range(const sph_case* c, double xlo, double xhi, const sph_fields* dst, uint32_t* gids,
+                        uint64_t* count);
+/* Histogram of particle x-coordinates over [0, box_x] in nbins equal bins, fluid and wall
+ * particles counted separately: for choosing slab planes that balance the load. */
+int sph_case_histogram_x(const sph_case* c, int32_t nbins, uint64_t* fluid_counts, uint64_t* wall_counts);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,8 @@ SYMBOLS = (
     "sph_zero_boundary_forces", "sph_step", "sph_sweeps", "sph_get_scalars", "sph_set_dt",
     "sph_density_reinit", "sph_neighbours", "sph_profile_enable", "sph_profile_read",
     "sph_case_default", "sph_case_params", "sph_case_init",
+    "sph_set_transport", "sph_upload_global_ids", "sph_rccl_unique_id", "sph_use_rccl",
+    "sph_case_init_range", "sph_case_histogram_x",
 )
 
 
@@ -35,7 +37,9 @@ class Params(C.Structure):
                 ("alpha", C.c_double), ("eps", C.c_double), ("g", C.c_double),
                 ("g_axis", C.c_int32), ("subits", C.c_int32), ("beta", C.c_double),
                 ("mass", C.c_double), ("dt0", C.c_double), ("skin_frac", C.c_double),
-                ("max_neighbours", C.c_int32), ("device", C.c_int32)]
+                ("max_neighbours", C.c_int32), ("device", C.c_int32),
+                ("rank", C.c_int32), ("nranks", C.c_int32), ("npts_global", C.c_uint64),
+                ("capacity", C.c_uint64), ("slab_lo", C.c_double), ("slab_hi", C.c_double)]
 
 
 class Fields(C.Structure):
@@ -57,6 +61,16 @@ class Case(C.Structure):
     _fields_ = [("program", C.c_int32), ("npart", C.c_int32 * 3), ("pstep", C.c_double),
                 ("box", C.c_double * 3), ("start", C.c_double * 3), ("dt0", C.c_double),
                 ("rho0", C.c_double), ("Cs", C.c_double), ("alpha", C.c_double), ("gravity", C.c_double)]
+
+
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                         C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("host_buffers", C.c_int32), ("sendrecv", SENDRECV_FN),
+                ("allreduce", ALLREDUCE_FN)]
 
 
 class SphError(RuntimeError):
@@ -98,12 +112,26 @@ def lib():
     L.sph_case_params.argtypes = [C.POINTER(Case), C.POINTER(Params), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]
     L.sph_case_init.argtypes = [C.POINTER(Case), C.POINTER(Fields)]
+    L.sph_set_transport.argtypes = [vp, C.POINTER(Transport)]
+    L.sph_upload_global_ids.argtypes = [vp, vp]
+    L.sph_rccl_unique_id.argtypes = [vp]
+    L.sph_use_rccl.argtypes = [vp, vp]
+    L.sph_case_init_range.argtypes = [C.POINTER(Case), C.c_double, C.c_double, C.POINTER(Fields), vp,
+                                      C.POINTER(C.c_uint64)]
+    L.sph_case_histogram_x.argtypes = [C.POINTER(Case), C.c_int32, vp, vp]
     _lib = L
     return L
 
 
 # ---------------------------------------------------------------------------------------------
 # cases
+
+
+def rccl_unique_id():
+    buf = (C.c_char * 128)()
+    if lib().sph_rccl_unique_id(buf) != OK:
+        raise SphError("sph_rccl_unique_id failed (is librccl.so.1 on the loader path?)")
+    return bytes(buf.raw)
 
 
 def default_case(program):
@@ -173,6 +201,28 @@ def case_init(case):
     return p, st
 
 
+def case_init_range(case, xlo, xhi):
+    """The particles of InitSPH with xlo <= x < xhi: (state dict, global indices)."""
+    p, _, _ = case_params(case)
+    cnt = C.c_uint64()
+    if lib().sph_case_init_range(C.byref(case), xlo, xhi, None, None, C.byref(cnt)) != OK:
+        raise SphError("sph_case_init_range failed")
+    n = int(cnt.value)
+    st = alloc_state(n, p.dim)
+    gids = np.zeros(n, np.uint32)
+    f = _fields(st, p.dim)
+    if lib().sph_case_init_range(C.byref(case), xlo, xhi, C.byref(f), gids.ctypes.data, C.byref(cnt)) != OK:
+        raise SphError("sph_case_init_range failed")
+    return st, gids
+
+
+def case_histogram_x(case, nbins):
+    fl, wl = np.zeros(nbins, np.uint64), np.zeros(nbins, np.uint64)
+    if lib().sph_case_histogram_x(C.byref(case), nbins, fl.ctypes.data, wl.ctypes.data) != OK:
+        raise SphError("sph_case_histogram_x failed")
+    return fl, wl
+
+
 # ---------------------------------------------------------------------------------------------
 
 
@@ -236,6 +286,20 @@ class Sim:
         if names is not None:
             st = {k: v for k, v in st.items() if k in names}
         return st
+
+    def set_transport(self, transport):
+        """Install a `Transport`; the object (and its callbacks) is kept alive by this Sim."""
+        self._transport = transport
+        self._chk(lib().sph_set_transport(self._h, C.byref(transport)), "sph_set_transport")
+
+    def use_rccl(self, unique_id):
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(lib().sph_use_rccl(self._h, buf), "sph_use_rccl")
+
+    def upload_global_ids(self, gids):
+        g = np.ascontiguousarray(gids, np.uint32)
+        assert g.shape == (self.npts,)
+        self._chk(lib().sph_upload_global_ids(self._h, g.ctypes.data), "sph_upload_global_ids")
 
     def forces(self, which):
         self._chk(lib().sph_forces(self._h, which), "sph_forces")

@@ -2,6 +2,8 @@
 #include "../../include/sph_amd.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -28,7 +30,10 @@ struct sph_ctx {
     DevParams dp;
     int dim = 0;
     bool xsph = false;
-    uint32_t n = 0, stride = 0, nblocks = 0, npairblocks = 0;
+    uint32_t n = 0;        /* particles this context owns */
+    uint32_t n_halo = 0;   /* neighbours' particles kept behind the owned ones (slab runs) */
+    uint32_t cap = 0;      /* room in every per-particle array */
+    uint32_t npairblocks = 0;
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -49,8 +54,10 @@ struct sph_ctx {
     float* pRrho_alt = nullptr;
     float* pp = nullptr; /* pressure of state n+1 (the records carry p/rho^2 instead) */
     float* pp_alt = nullptr;
-    uint32_t* id = nullptr;
+    uint32_t* id = nullptr; /* position in the caller's arrays; SPH_HALO_ID for halo particles */
     uint32_t* id_alt = nullptr;
+    uint32_t* gid = nullptr; /* global original index (slab runs); the wall test reads it */
+    uint32_t* gid_alt = nullptr;
 
     /* sort, cells, candidate lists */
     uint32_t *keys = nullptr, *keys_alt = nullptr, *perm = nullptr, *perm_alt = nullptr;
@@ -59,6 +66,7 @@ struct sph_ctx {
     uint32_t* bsum = nullptr;
     size_t bsum_cap = 0;
     uint32_t *cbeg = nullptr, *cend = nullptr;
+    uint32_t *hbeg = nullptr, *hend = nullptr; /* cell table of the halo particles */
     size_t cell_cap = 0;
     uint32_t* nbr = nullptr;
     uint32_t cap_k = 0;
@@ -77,11 +85,32 @@ struct sph_ctx {
     double* part2 = nullptr; /* their first fold */
     double* bbox_part = nullptr;
     double* bbox_host = nullptr; /* pinned */
-    uint32_t* need_host = nullptr;
-    void* tmp = nullptr; /* n * 8 bytes staging, original order */
+    uint32_t* need_host = nullptr; /* pinned, 8 words */
+    void* tmp = nullptr; /* cap * 8 bytes staging, original order */
 
     uint64_t rebuilds = 0, redos = 0;
     bool uploaded_n = false, uploaded_np1 = false;
+
+    /* slab decomposition */
+    bool dist = false;
+    int rank = 0, nranks = 1;
+    bool has_side[2] = {false, false}; /* a neighbour on the left / right */
+    uint32_t halo_cap = 0;             /* per side */
+    uint32_t nsend[2] = {0, 0}, nrecv[2] = {0, 0};
+    uint32_t* send_idx = nullptr;  /* [2][halo_cap] cell-order positions of the particles sent */
+    uint32_t* halo_pos = nullptr;  /* [2*halo_cap] where the k-th received particle lives */
+    Rec *sendbuf = nullptr, *recvbuf = nullptr; /* [2][halo_cap] */
+    uint32_t *sendgid = nullptr, *recvgid = nullptr;
+    char *h_send = nullptr, *h_recv = nullptr; /* pinned staging for host transports */
+    uint32_t *flags = nullptr, *fpos = nullptr;
+    hipStream_t comm = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_recvd = nullptr;
+    sph_transport tr;
+    bool have_tr = false;
+    double* red_dev = nullptr;
+    uint32_t iL_end = 0, iR_begin = 0; /* owned ranges [0,iL_end) and [iR_begin,n) touch a halo */
+    void* rccl = nullptr;              /* state of the built-in RCCL transport */
+    void (*rccl_free)(void*) = nullptr;
 
     /* pair-kernel timing */
     bool profile = false;
@@ -113,7 +142,8 @@ constexpr int BBOX_BLOCKS = 1024;
         if (r_ != SPH_OK) return r_;  \
     } while (0)
 
-inline uint32_t nblk(uint32_t n) { return (n + SPH_BLOCK - 1) / SPH_BLOCK; }
+inline uint32_t nblk(uint32_t n) { return std::max(1u, (n + SPH_BLOCK - 1) / SPH_BLOCK); }
+inline uint32_t pairblocks(uint32_t count) { return ((count + PAIR_PARTICLES - 1) / PAIR_PARTICLES + 7u) & ~7u; }
 
 template <typename T>
 int dalloc(sph_ctx* c, T** p, size_t count) {
@@ -133,6 +163,10 @@ inline int NVV(int d) { return 6 + d; }
 inline int NF(int d) { return 9 + d; }
 enum { F_RHO = 0, F_RRHO = 1, F_P = 2, F_M = 3 };
 
+inline uint32_t n_local(const sph_ctx* c) { return c->n + c->n_halo; }
+/* the array the wall test reads: global ids in a slab run, upload positions otherwise */
+inline const uint32_t* wall_ids(const sph_ctx* c) { return c->dist ? c->gid : c->id; }
+
 int exclusive_scan(sph_ctx* c, const uint32_t* in, uint32_t* out, uint32_t n) {
     const uint32_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb > c->bsum_cap) {
@@ -148,10 +182,12 @@ int exclusive_scan(sph_ctx* c, const uint32_t* in, uint32_t* out, uint32_t n) {
     return SPH_OK;
 }
 
-/* keys (unsorted, in c->keys) -> c->keys sorted, c->perm = sorted position -> old index */
-int radix_sort(sph_ctx* c, uint32_t ncells) {
-    const uint32_t n = c->n;
-    const uint32_t nb = (n + RS_TILE - 1) / RS_TILE;
+/* Sorts m (key, position) pairs; on return `keys` holds the sorted keys and `perm` the old
+ * position of each sorted entry (the four pointers are swapped as the passes ping-pong). */
+int radix_sort(sph_ctx* c, uint32_t*& keys, uint32_t*& keys_alt, uint32_t*& perm, uint32_t*& perm_alt, uint32_t m,
+               uint32_t ncells) {
+    if (m == 0) return SPH_OK;
+    const uint32_t nb = (m + RS_TILE - 1) / RS_TILE;
     const size_t hsz = (size_t)256 * nb;
     if (hsz > c->hist_cap) {
         if (c->hist) HIPCHK(hipFree(c->hist));
@@ -165,32 +201,37 @@ int radix_sort(sph_ctx* c, uint32_t ncells) {
     const uint32_t* vin = nullptr;
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(SPH_BLOCK), 0, c->stream, c->keys, n, shift, c->hist, nb);
+        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(SPH_BLOCK), 0, c->stream, keys, m, shift, c->hist, nb);
         CHK(exclusive_scan(c, c->hist, c->hist, (uint32_t)hsz));
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(SPH_BLOCK), 0, c->stream, c->keys, vin, c->keys_alt,
-                           c->perm_alt, n, shift, c->hist, nb);
-        std::swap(c->keys, c->keys_alt);
-        std::swap(c->perm, c->perm_alt);
-        vin = c->perm;
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(SPH_BLOCK), 0, c->stream, keys, vin, keys_alt, perm_alt, m, shift,
+                           c->hist, nb);
+        std::swap(keys, keys_alt);
+        std::swap(perm, perm_alt);
+        vin = perm;
     }
     HIPCHK(hipGetLastError());
     return SPH_OK;
 }
 
-template <int DIM>
-void launch_hash(sph_ctx* c, const Rec* r) {
-    hipLaunchKernelGGL(k_hash<DIM>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->n, c->grid, c->keys);
+void launch_hash(sph_ctx* c, const Rec* r, uint32_t m, uint32_t* keys) {
+    if (m == 0) return;
+    if (c->dim == 3) hipLaunchKernelGGL(k_hash<3>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, c->grid, keys);
+    else hipLaunchKernelGGL(k_hash<2>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, c->grid, keys);
 }
 
 int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
+    const uint32_t* hb = c->n_halo ? c->hbeg : nullptr;
+    const uint32_t* he = c->n_halo ? c->hend : nullptr;
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
         if (c->dim == 3)
-            hipLaunchKernelGGL(k_build_list<3>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->n,
-                               c->grid, c->cbeg, c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, c->id, wall_below);
+            hipLaunchKernelGGL(k_build_list<3>, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, c->n, c->grid, c->cbeg,
+                               c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_ids(c), wall_below,
+                               hb, he);
         else
-            hipLaunchKernelGGL(k_build_list<2>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->n,
-                               c->grid, c->cbeg, c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, c->id, wall_below);
+            hipLaunchKernelGGL(k_build_list<2>, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, c->n, c->grid, c->cbeg,
+                               c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_ids(c), wall_below,
+                               hb, he);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -200,17 +241,155 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
         const uint32_t newcap = (need + need / 8 + 7u) & ~3u;
         HIPCHK(hipFree(c->nbr));
         c->nbr = nullptr;
-        CHK(dalloc(c, &c->nbr, (size_t)newcap * c->stride));
+        CHK(dalloc(c, &c->nbr, (size_t)newcap * c->n));
         c->cap_k = newcap;
     }
     return fail(c, SPH_ESTATE, "candidate lists kept overflowing");
 }
 
+/* ---- transport helpers (slab runs) --------------------------------------------------------- */
+
+/* Exchange device buffers with the slab neighbours on the communication stream.  Byte counts
+ * of a side without a neighbour are zero. */
+int exchange_bytes(sph_ctx* c, const void* sL, size_t nsL, void* rL, size_t nrL, const void* sR, size_t nsR, void* rR,
+                   size_t nrR) {
+    if (!c->tr.host_buffers) {
+        if (c->tr.sendrecv(c->tr.user, sL, nsL, rL, nrL, sR, nsR, rR, nrR, (void*)c->comm) != 0)
+            return fail(c, SPH_ECOMM, "transport sendrecv failed");
+        return SPH_OK;
+    }
+    const size_t half = (size_t)c->halo_cap * sizeof(Rec);
+    if (nsL) HIPCHK(hipMemcpyAsync(c->h_send, sL, nsL, hipMemcpyDeviceToHost, c->comm));
+    if (nsR) HIPCHK(hipMemcpyAsync(c->h_send + half, sR, nsR, hipMemcpyDeviceToHost, c->comm));
+    HIPCHK(hipStreamSynchronize(c->comm));
+    if (c->tr.sendrecv(c->tr.user, c->h_send, nsL, c->h_recv, nrL, c->h_send + half, nsR, c->h_recv + half, nrR, nullptr) != 0)
+        return fail(c, SPH_ECOMM, "transport sendrecv failed");
+    if (nrL) HIPCHK(hipMemcpyAsync(rL, c->h_recv, nrL, hipMemcpyHostToDevice, c->comm));
+    if (nrR) HIPCHK(hipMemcpyAsync(rR, c->h_recv + half, nrR, hipMemcpyHostToDevice, c->comm));
+    return SPH_OK;
+}
+
+/* In-place all-reduce of a few host doubles (op 0 = max, 1 = sum). */
+int allreduce_host(sph_ctx* c, double* vals, int n, int op) {
+    if (!c->dist) return SPH_OK;
+    if (c->tr.host_buffers) {
+        if (c->tr.allreduce(c->tr.user, vals, n, op, nullptr) != 0) return fail(c, SPH_ECOMM, "transport allreduce failed");
+        return SPH_OK;
+    }
+    HIPCHK(hipMemcpyAsync(c->red_dev, vals, sizeof(double) * n, hipMemcpyHostToDevice, c->comm));
+    if (c->tr.allreduce(c->tr.user, c->red_dev, n, op, (void*)c->comm) != 0)
+        return fail(c, SPH_ECOMM, "transport allreduce failed");
+    HIPCHK(hipMemcpyAsync(vals, c->red_dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->comm));
+    HIPCHK(hipStreamSynchronize(c->comm));
+    return SPH_OK;
+}
+
+/* Selects the owned particles each neighbour needs (x <= thr[0] for the left one, x >= thr[1]
+ * for the right one; ascending cell-order positions), sends their records and global ids, and
+ * places what arrives behind the owned particles of record buffer `src`, sorted by cell. */
+int exchange_halo_at_rebuild(sph_ctx* c, int src, const double thr[2]) {
+    const uint32_t n = c->n;
+    uint32_t counts[2] = {0, 0};
+    for (int side = 0; side < 2; ++side) {
+        if (!c->has_side[side]) continue;
+        hipLaunchKernelGGL(k_flag_halo, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->rec[src], n, side, thr[side],
+                           c->flags);
+        CHK(exclusive_scan(c, c->flags, c->fpos, n));
+        hipLaunchKernelGGL(k_compact, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->flags, c->fpos, n, c->halo_cap,
+                           c->send_idx + (size_t)side * c->halo_cap);
+        HIPCHK(hipGetLastError());
+        /* count = last scan value + last flag */
+        HIPCHK(hipMemcpyAsync(&c->need_host[2 + side * 2], c->fpos + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&c->need_host[3 + side * 2], c->flags + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        counts[side] = c->need_host[2 + side * 2] + c->need_host[3 + side * 2];
+        if (counts[side] > c->halo_cap) counts[side] = UINT32_MAX; /* reported after the ranks have compared notes */
+    }
+    {
+        /* an overflow anywhere stops every rank here, before anyone waits for a message */
+        double over[1] = {(counts[0] == UINT32_MAX || counts[1] == UINT32_MAX) ? 1.0 : 0.0};
+        CHK(allreduce_host(c, over, 1, 0));
+        if (over[0] != 0.0) return fail(c, SPH_ENOMEM, "halo larger than the capacity given at sph_create (on some rank)");
+    }
+    c->nsend[0] = counts[0];
+    c->nsend[1] = counts[1];
+    /* pack records and global ids */
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t m = c->nsend[side];
+        if (!m) continue;
+        const size_t off = (size_t)side * c->halo_cap;
+        hipLaunchKernelGGL(k_gather_rec, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, c->rec[src], c->send_idx + off, m,
+                           c->sendbuf + off);
+        hipLaunchKernelGGL(k_gather_u32, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, c->gid, c->send_idx + off, m,
+                           c->sendgid + off);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    /* counts first: through the same transport, as 8-byte messages in the staging buffers */
+    {
+        uint64_t s[2] = {c->nsend[0], c->nsend[1]}, r[2] = {0, 0};
+        uint64_t* ds = (uint64_t*)c->red_dev; /* scratch: [0..1] send, [2..3] recv */
+        HIPCHK(hipMemcpyAsync(ds, s, sizeof s, hipMemcpyHostToDevice, c->comm));
+        HIPCHK(hipMemsetAsync(ds + 2, 0, 16, c->comm));
+        CHK(exchange_bytes(c, ds, c->has_side[0] ? 8 : 0, ds + 2, c->has_side[0] ? 8 : 0, ds + 1, c->has_side[1] ? 8 : 0,
+                           ds + 3, c->has_side[1] ? 8 : 0));
+        HIPCHK(hipMemcpyAsync(r, ds + 2, sizeof r, hipMemcpyDeviceToHost, c->comm));
+        HIPCHK(hipStreamSynchronize(c->comm));
+        if (r[0] > c->halo_cap || r[1] > c->halo_cap)
+            return fail(c, SPH_ENOMEM, "incoming halo larger than the capacity given at sph_create");
+        c->nrecv[0] = (uint32_t)r[0];
+        c->nrecv[1] = (uint32_t)r[1];
+    }
+    const size_t hc = c->halo_cap;
+    CHK(exchange_bytes(c, c->sendbuf, (size_t)c->nsend[0] * sizeof(Rec), c->recvbuf, (size_t)c->nrecv[0] * sizeof(Rec),
+                       c->sendbuf + hc, (size_t)c->nsend[1] * sizeof(Rec), c->recvbuf + hc,
+                       (size_t)c->nrecv[1] * sizeof(Rec)));
+    HIPCHK(hipStreamSynchronize(c->comm));
+    CHK(exchange_bytes(c, c->sendgid, (size_t)c->nsend[0] * 4, c->recvgid, (size_t)c->nrecv[0] * 4, c->sendgid + hc,
+                       (size_t)c->nsend[1] * 4, c->recvgid + hc, (size_t)c->nrecv[1] * 4));
+    HIPCHK(hipStreamSynchronize(c->comm));
+
+    /* place behind the owned particles: left block, then right block */
+    const uint32_t m = c->nrecv[0] + c->nrecv[1];
+    if (n + m > c->cap) return fail(c, SPH_ENOMEM, "owned + halo particles exceed the capacity");
+    Rec* r = c->rec[src];
+    if (c->nrecv[0]) {
+        HIPCHK(hipMemcpyAsync(r + n, c->recvbuf, (size_t)c->nrecv[0] * sizeof(Rec), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->gid + n, c->recvgid, (size_t)c->nrecv[0] * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (c->nrecv[1]) {
+        HIPCHK(hipMemcpyAsync(r + n + c->nrecv[0], c->recvbuf + hc, (size_t)c->nrecv[1] * sizeof(Rec), hipMemcpyDeviceToDevice,
+                              c->stream));
+        HIPCHK(hipMemcpyAsync(c->gid + n + c->nrecv[0], c->recvgid + hc, (size_t)c->nrecv[1] * 4, hipMemcpyDeviceToDevice,
+                              c->stream));
+    }
+    c->n_halo = m;
+    if (m == 0) return SPH_OK;
+    hipLaunchKernelGGL(k_fill<uint32_t>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, c->id + n, SPH_HALO_ID, m);
+    /* sort the halo region by cell */
+    launch_hash(c, r + n, m, c->keys + n);
+    uint32_t *k = c->keys + n, *ka = c->keys_alt + n, *p = c->perm + n, *pa = c->perm_alt + n;
+    CHK(radix_sort(c, k, ka, p, pa, m, c->grid.ncells));
+    if (k != c->keys + n) HIPCHK(hipMemcpyAsync(c->keys + n, k, (size_t)m * 4, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_reorder_halo, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, p, m, r + n, c->rec_alt + n, c->gid + n,
+                       c->gid_alt + n);
+    HIPCHK(hipMemcpyAsync(r + n, c->rec_alt + n, (size_t)m * sizeof(Rec), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->gid + n, c->gid_alt + n, (size_t)m * 4, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_halo_pos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, p, m, n, c->halo_pos);
+    HIPCHK(hipMemsetAsync(c->hbeg, 0xFF, sizeof(uint32_t) * c->grid.ncells, c->stream));
+    HIPCHK(hipMemsetAsync(c->hend, 0, sizeof(uint32_t) * c->grid.ncells, c->stream));
+    hipLaunchKernelGGL(k_cell_mark, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, c->keys + n, m, n, c->hbeg, c->hend);
+    HIPCHK(hipGetLastError());
+    return SPH_OK;
+}
+
 /* Re-bin on the positions held in record buffer `src`, bring every live array into the new
- * cell order, rebuild cell table and candidate lists, reset the travel bound. */
+ * cell order, (slab runs) fetch the neighbours' boundary particles, rebuild cell table and
+ * candidate lists, reset the travel bound.  Collective in a slab run. */
 int rebuild(sph_ctx* c, int src, bool for_step = false) {
     const uint32_t n = c->n;
     const int dim = c->dim;
+    if (c->dist && !c->have_tr) return fail(c, SPH_ESTATE, "no transport installed (sph_set_transport / sph_use_rccl)");
     EventPair* ev = nullptr;
     if (c->profile) {
         if (c->rb_used == c->rb_pool.size()) {
@@ -222,21 +401,80 @@ int rebuild(sph_ctx* c, int src, bool for_step = false) {
         ev = &c->rb_pool[c->rb_used++];
         HIPCHK(hipEventRecord(ev->a, c->stream));
     }
+    c->n_halo = 0; /* the neighbours' particles are fetched afresh below */
+
+    /* inside a step, wall-wall pairs can be dropped while the walls are at rest */
+    double walls_move = 1.0;
+    if (for_step && c->dp.bound_parts > 0) {
+        WallRestArgs w;
+        memset(&w, 0, sizeof w);
+        w.n = n;
+        w.wall_below = c->dp.bound_parts;
+        w.dim = dim;
+        w.xsph = c->xsph;
+        w.rec = c->rec[src];
+        for (int d = 0; d < 3; ++d) {
+            w.nv[d] = c->nd[NV(d)];
+            w.nV[d] = c->nd[NVV(d)];
+            w.nf[d] = c->nd[NF(d)];
+        }
+        w.id = wall_ids(c);
+        HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k_walls_at_rest, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, w, c->need);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    }
     /* bounding box */
     hipLaunchKernelGGL(k_bbox, dim3(BBOX_BLOCKS), dim3(SPH_BLOCK), 0, c->stream, c->rec[src], n, dim, c->bbox_part);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->bbox_host, c->bbox_part, sizeof(double) * 6 * BBOX_BLOCKS, hipMemcpyDeviceToHost,
-                          c->stream));
+    HIPCHK(hipMemcpyAsync(c->bbox_host, c->bbox_part, sizeof(double) * 6 * BBOX_BLOCKS, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (for_step && c->dp.bound_parts > 0) walls_move = *c->need_host ? 1.0 : 0.0;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int b = 0; b < BBOX_BLOCKS; ++b)
         for (int d = 0; d < 3; ++d) {
             lo[d] = std::min(lo[d], c->bbox_host[b * 6 + d]);
             hi[d] = std::max(hi[d], c->bbox_host[b * 6 + 3 + d]);
         }
-    /* cell edge: candidate radius plus a relative margin that covers the rounding of the
-     * cell-coordinate arithmetic */
     const double r_list = std::sqrt(c->prm.search_radius_sq) * (1.0 + c->skin_frac);
+    const double reach = r_list * (1.0 + 1e-6); /* halo selection distance beyond a neighbour's extent */
+    double thr_send[2] = {0, 0};
+    if (c->dist) {
+        /* The ranks agree on: whether wall-wall pairs may be dropped; the y/z extent of the
+         * whole set (halo particles lie wherever the neighbours' particles are); and every
+         * rank's x-extent.  A rank sends its neighbour what lies within `reach` of that
+         * neighbour's extent, so particles that have drifted across a plane are still served. */
+        const int R = c->nranks;
+        std::vector<double> v(5 + 2 * (size_t)R, -1e300);
+        v[0] = walls_move;
+        v[1] = dim > 1 ? -lo[1] : 0; v[2] = dim > 1 ? hi[1] : 0;
+        v[3] = dim > 2 ? -lo[2] : 0; v[4] = dim > 2 ? hi[2] : 0;
+        v[5 + 2 * c->rank] = -lo[0];
+        v[6 + 2 * c->rank] = hi[0];
+        CHK(allreduce_host(c, v.data(), (int)v.size(), 0));
+        walls_move = v[0];
+        if (dim > 1) { lo[1] = -v[1]; hi[1] = v[2]; }
+        if (dim > 2) { lo[2] = -v[3]; hi[2] = v[4]; }
+        /* only adjacent slabs may interact; every rank sees the same table and stops together */
+        for (int r = 0; r + 2 < R; ++r)
+            if (!(-v[5 + 2 * (r + 2)] - v[6 + 2 * r] > reach))
+                return fail(c, SPH_ESTATE, "slabs thinner than the interaction range: non-adjacent ranks would interact");
+        if (c->has_side[0]) {
+            thr_send[0] = v[6 + 2 * (c->rank - 1)] + reach; /* left neighbour's largest x, plus reach */
+            lo[0] = lo[0] - reach;                           /* what the left neighbour sends: x >= this */
+        }
+        if (c->has_side[1]) {
+            thr_send[1] = -v[5 + 2 * (c->rank + 1)] - reach;
+            hi[0] = hi[0] + reach;
+        }
+    }
+    for (int d = 0; d < dim; ++d)
+        if (!(hi[d] >= lo[d])) { lo[d] = 0; hi[d] = 0; } /* no finite particle */
+
+    /* Cells of edge >= the candidate radius (plus a relative margin that covers the rounding
+     * of the cell-coordinate arithmetic), in bricks of 2^brick_log2 cells per axis; the grid
+     * is padded to whole bricks.  If a stray particle blew the box up, stretch the cells
+     * until the table fits its allocation. */
     GridParams g;
     memset(&g, 0, sizeof g);
     for (int d = 0; d < 3; ++d) {
@@ -246,10 +484,6 @@ int rebuild(sph_ctx* c, int src, bool for_step = false) {
         g.nt[d] = 1;
         g.ts[d] = 0;
     }
-    for (int d = 0; d < dim; ++d)
-        if (!(hi[d] >= lo[d])) { lo[d] = 0; hi[d] = 0; } /* no finite particle */
-    /* bricks of 2^brick_log2 cells per axis; the grid is padded to whole bricks.  If a stray
-     * particle blew the box up, stretch the cells until the table fits its allocation. */
     double edge = r_list * (1.0 + 1e-9);
     uint64_t ncells = 0;
     for (int attempt = 0; attempt < 200; ++attempt) {
@@ -257,8 +491,7 @@ int rebuild(sph_ctx* c, int src, bool for_step = false) {
         for (int d = 0; d < dim; ++d) {
             const double cells = std::floor((hi[d] - lo[d]) / edge) + 1.0;
             const double tb = (double)(1u << c->brick_log2);
-            const double nt = std::ceil(cells / tb);
-            tot *= nt * tb;
+            tot *= std::ceil(cells / tb) * tb;
         }
         if (tot <= (double)c->cell_cap && tot < 2147483648.0) {
             ncells = 1;
@@ -280,9 +513,9 @@ int rebuild(sph_ctx* c, int src, bool for_step = false) {
     g.ncells = (uint32_t)ncells;
     c->grid = g;
 
-    if (dim == 3) launch_hash<3>(c, c->rec[src]);
-    else launch_hash<2>(c, c->rec[src]);
-    CHK(radix_sort(c, g.ncells));
+    /* sort the owned particles by cell */
+    launch_hash(c, c->rec[src], n, c->keys);
+    CHK(radix_sort(c, c->keys, c->keys_alt, c->perm, c->perm_alt, n, g.ncells));
 
     /* physical reorder of every live array */
     ReorderArgs a;
@@ -321,7 +554,7 @@ int rebuild(sph_ctx* c, int src, bool for_step = false) {
     a.rs[0] = c->rec[c->b0];
     a.rd[0] = c->rec_alt;
     a.nr = 1;
-    Rec* spare = nullptr;
+    bool carried = false;
     if (src != c->b0) {
         /* positions came from a scratch buffer: carry it along through a free record buffer */
         int freeb = 0;
@@ -329,11 +562,15 @@ int rebuild(sph_ctx* c, int src, bool for_step = false) {
         a.rs[1] = c->rec[src];
         a.rd[1] = c->rec[freeb];
         a.nr = 2;
-        spare = c->rec[freeb];
+        carried = true;
     }
     a.ids = c->id;
     a.idd = c->id_alt;
-    hipLaunchKernelGGL(k_reorder, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, a);
+    if (c->dist) {
+        a.gids = c->gid;
+        a.gidd = c->gid_alt;
+    }
+    hipLaunchKernelGGL(k_reorder, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     for (int q = 0; q < n_nd; ++q) std::swap(c->nd[map_nd[q]], c->nd_alt[map_nd[q]]);
     for (int q = n_nd; q < k; ++q) std::swap(c->pd[map_pd[q - n_nd]], c->pd_alt[map_pd[q - n_nd]]);
@@ -342,43 +579,45 @@ int rebuild(sph_ctx* c, int src, bool for_step = false) {
     std::swap(c->pp, c->pp_alt);
     std::swap(c->rec[c->b0], c->rec_alt);
     std::swap(c->id, c->id_alt);
-    if (spare) {
+    if (c->dist) std::swap(c->gid, c->gid_alt);
+    if (carried) {
         int freeb = 0;
         while (freeb == src || freeb == c->b0) ++freeb;
         std::swap(c->rec[src], c->rec[freeb]);
     }
 
-    /* cell table */
+    /* cell table of the owned particles */
     HIPCHK(hipMemsetAsync(c->cbeg, 0xFF, sizeof(uint32_t) * g.ncells, c->stream));
     HIPCHK(hipMemsetAsync(c->cend, 0, sizeof(uint32_t) * g.ncells, c->stream));
-    hipLaunchKernelGGL(k_cell_mark, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, c->keys, n, c->cbeg, c->cend);
+    hipLaunchKernelGGL(k_cell_mark, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->keys, n, 0u, c->cbeg, c->cend);
     HIPCHK(hipGetLastError());
+
+    if (c->dist) {
+        CHK(exchange_halo_at_rebuild(c, src, thr_send));
+        /* Owned particles that can see a halo particle, and all those sent to a neighbour, have
+         * x <= thr_send[0] or x >= thr_send[1]: with bricks numbered x-slowest they sit in the
+         * first / last few brick columns, contiguous ranges of the cell order. */
+        const uint32_t col = ((uint32_t)g.nt[1] * (uint32_t)(dim == 3 ? g.nt[2] : 1)) << (g.ts[0] + g.ts[1] + (dim == 3 ? g.ts[2] : 0));
+        const uint32_t cols = (uint32_t)g.nt[0];
+        auto cellx = [&](double x) {
+            double cc = std::floor((x - g.lo[0]) * g.inv[0]);
+            cc = std::max(cc, 0.0);
+            cc = std::min(cc, (double)(g.n[0] - 1));
+            return (uint32_t)cc;
+        };
+        const uint32_t colsL = c->has_side[0] ? std::min(cols, (cellx(thr_send[0]) >> g.ts[0]) + 1u) : 0u;
+        const uint32_t colR0 = c->has_side[1] ? (cellx(thr_send[1]) >> g.ts[0]) : cols;
+        hipLaunchKernelGGL(k_lower_bounds, dim3(1), dim3(1), 0, c->stream, c->keys, n, colsL * col, colR0 * col, c->need + 2);
+        HIPCHK(hipMemcpyAsync(c->need_host + 6, c->need + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->iL_end = c->has_side[0] ? c->need_host[6] : 0;
+        c->iR_begin = c->has_side[1] ? c->need_host[7] : n;
+        if (c->iL_end > c->iR_begin) c->iL_end = c->iR_begin; /* thin slab: the two layers overlap, every particle is in one */
+    }
 
     c->r_list2 = r_list * r_list;
     c->disp_limit = 0.5 * (r_list - std::sqrt(c->prm.search_radius_sq)) * 0.999;
-    /* inside a step, wall-wall pairs can be dropped while the walls are at rest */
-    uint32_t wall_below = 0;
-    if (for_step && c->dp.bound_parts > 0) {
-        WallRestArgs w;
-        memset(&w, 0, sizeof w);
-        w.n = n;
-        w.wall_below = c->dp.bound_parts;
-        w.dim = dim;
-        w.xsph = c->xsph;
-        w.rec = c->rec[src];
-        for (int d = 0; d < 3; ++d) {
-            w.nv[d] = c->nd[NV(d)];
-            w.nV[d] = c->nd[NVV(d)];
-            w.nf[d] = c->nd[NF(d)];
-        }
-        w.id = c->id;
-        HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL(k_walls_at_rest, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, w, c->need);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (*c->need_host == 0) wall_below = c->dp.bound_parts;
-    }
+    const uint32_t wall_below = (for_step && c->dp.bound_parts > 0 && walls_move == 0.0) ? c->dp.bound_parts : 0u;
     CHK(build_lists(c, c->rec[src], wall_below));
     c->lists_for_step = for_step;
 
@@ -416,14 +655,19 @@ NState n_state(sph_ctx* c) {
     return s;
 }
 
+/* Launches the pair kernel over particles [first, first+count); its workgroups leave their
+ * partials in slots [part_base, part_base + grid) of each field of c->part. */
 template <bool FUSED>
-int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out, int zero_wall) {
+int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out, int zero_wall, uint32_t first,
+                uint32_t count, uint32_t part_base, uint32_t part_n) {
+    if (count == 0) return SPH_OK;
     NState ns = n_state(c);
-    dim3 g(c->npairblocks), b(SPH_BLOCK);
+    dim3 g(pairblocks(count)), b(SPH_BLOCK);
     static const int dbg = getenv("SPH_DBG") ? atoi(getenv("SPH_DBG")) : 0; /* timing experiments only */
-#define LP(D, X)                                                                                               \
-    hipLaunchKernelGGL((k_pair<D, X, FUSED>), g, b, 0, c->stream, c->dp, rin, c->nbr, c->cap_k, c->cnt, o,     \
-                       store_out, zero_wall, ns, c->id, rout, c->pp, c->S, c->part, dbg)
+#define LP(D, X)                                                                                                \
+    hipLaunchKernelGGL((k_pair<D, X, FUSED>), g, b, 0, c->stream, c->dp, rin, c->nbr, c->cap_k, c->cnt, o,      \
+                       store_out, zero_wall, ns, wall_ids(c), rout, c->pp, c->S, c->part, dbg, first, count,    \
+                       part_base, part_n)
     if (c->dim == 3) LP(3, true);
     else if (c->xsph) LP(2, true);
     else LP(2, false);
@@ -444,7 +688,7 @@ int pack_n_into(sph_ctx* c, Rec* dst) {
     a.p = c->nfl[F_P];
     a.m = c->nfl[F_M];
     a.rec = dst;
-    hipLaunchKernelGGL(k_pack, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, a);
+    hipLaunchKernelGGL(k_pack, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return SPH_OK;
 }
@@ -467,6 +711,49 @@ void fill_scalars(sph_ctx* c, sph_scalars* out) {
     out->list_rebuilds = c->rebuilds;
     out->step_redos = c->redos;
     out->hit_pairs = s.hit_pairs;
+}
+
+/* One sweep's pair/update launches.  A single domain is one launch.  A slab first does the
+ * layers next to its neighbours, hands their new records to the transport on the
+ * communication stream, and computes its interior while they travel. */
+int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, uint32_t* part_n_out) {
+    const uint32_t n = c->n;
+    OutState o = out_state(c, SPH_STATE_NP1);
+    if (!c->dist) {
+        *part_n_out = pairblocks(n);
+        return launch_pair<true>(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 1, 0, n, 0, *part_n_out);
+    }
+    const uint32_t nL = c->iL_end, nR = n - c->iR_begin, nI = c->iR_begin - c->iL_end;
+    const uint32_t bL = nL ? pairblocks(nL) : 0, bR = nR ? pairblocks(nR) : 0, bI = nI ? pairblocks(nI) : 0;
+    const uint32_t part_n = bL + bR + bI;
+    *part_n_out = part_n;
+    CHK(launch_pair<true>(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 1, 0, nL, 0, part_n));
+    CHK(launch_pair<true>(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 1, c->iR_begin, nR, bL, part_n));
+    const size_t hc = c->halo_cap;
+    for (int side = 0; side < 2; ++side)
+        if (c->nsend[side])
+            hipLaunchKernelGGL(k_gather_rec, dim3(nblk(c->nsend[side])), dim3(SPH_BLOCK), 0, c->stream, c->rec[nxt],
+                               c->send_idx + side * hc, c->nsend[side], c->sendbuf + side * hc);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev_packed, c->stream));
+    CHK(launch_pair<true>(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 1, c->iL_end, nI, bL + bR, part_n));
+    /* the exchange runs beside the interior launch */
+    HIPCHK(hipStreamWaitEvent(c->comm, c->ev_packed, 0));
+    CHK(exchange_bytes(c, c->sendbuf, (size_t)c->nsend[0] * sizeof(Rec), c->recvbuf, (size_t)c->nrecv[0] * sizeof(Rec),
+                       c->sendbuf + hc, (size_t)c->nsend[1] * sizeof(Rec), c->recvbuf + hc,
+                       (size_t)c->nrecv[1] * sizeof(Rec)));
+    HIPCHK(hipEventRecord(c->ev_recvd, c->comm));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_recvd, 0));
+    /* received records go where the halo particles live in this rank's cell order; the
+     * receive buffer holds the left block at 0 and the right block at halo_cap */
+    if (c->nrecv[0])
+        hipLaunchKernelGGL(k_scatter_rec, dim3(nblk(c->nrecv[0])), dim3(SPH_BLOCK), 0, c->stream, c->recvbuf, c->halo_pos, 0u,
+                           c->nrecv[0], c->rec[nxt]);
+    if (c->nrecv[1])
+        hipLaunchKernelGGL(k_scatter_rec, dim3(nblk(c->nrecv[1])), dim3(SPH_BLOCK), 0, c->stream, c->recvbuf + hc,
+                           c->halo_pos + c->nrecv[0], 0u, c->nrecv[1], c->rec[nxt]);
+    HIPCHK(hipGetLastError());
+    return SPH_OK;
 }
 
 /* One Newmark_Beta call, or its first `nsweeps` sweeps when partial. */
@@ -501,39 +788,58 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
                 ev = &c->ev_pool[c->ev_used++];
                 HIPCHK(hipEventRecord(ev->a, c->stream));
             }
-            CHK(launch_pair<true>(c, c->rec[cur], c->rec[nxt], out_state(c, SPH_STATE_NP1), last ? 1 : 0, 1));
+            uint32_t part_n = 0;
+            CHK(sweep_launches(c, cur, nxt, last, &part_n));
             if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
-            hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS), dim3(SPH_BLOCK), 0, c->stream, c->part, c->npairblocks,
-                               PART_FIELDS, c->part2);
+            hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS), dim3(SPH_BLOCK), 0, c->stream, c->part, part_n, PART_FIELDS,
+                               c->part2);
             hipLaunchKernelGGL(k_sweep_finalize, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->part2, k,
                                (last && !partial) ? 1 : (last ? 2 : 0), mode < 2 ? 1 : 0);
             cur = nxt;
         }
-        if (!partial) {
-            CommitArgs a;
-            memset(&a, 0, sizeof a);
-            a.n = c->n;
-            a.dim = c->dim;
-            a.xsph = c->xsph;
-            a.rec = c->rec[cur];
-            for (int d = 0; d < 3; ++d) {
-                a.pf[d] = c->pd[d];
-                a.pV[d] = c->pd[3 + d];
-                a.nx[d] = c->nd[NX(d)];
-                a.nv[d] = c->nd[NV(d)];
-                a.nV[d] = c->nd[NVV(d)];
-                a.nf[d] = c->nd[NF(d)];
-            }
-            a.pRrho = c->pRrho;
-            a.pp = c->pp;
-            a.nrho = c->nfl[F_RHO];
-            a.np = c->nfl[F_P];
-            a.nRrho = c->nfl[F_RRHO];
-            hipLaunchKernelGGL(k_commit, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, a, c->S);
+        CommitArgs a;
+        memset(&a, 0, sizeof a);
+        a.n = c->n;
+        a.dim = c->dim;
+        a.xsph = c->xsph;
+        a.rec = c->rec[cur];
+        for (int d = 0; d < 3; ++d) {
+            a.pf[d] = c->pd[d];
+            a.pV[d] = c->pd[3 + d];
+            a.nx[d] = c->nd[NX(d)];
+            a.nv[d] = c->nd[NV(d)];
+            a.nV[d] = c->nd[NVV(d)];
+            a.nf[d] = c->nd[NF(d)];
+        }
+        a.pRrho = c->pRrho;
+        a.pp = c->pp;
+        a.nrho = c->nfl[F_RHO];
+        a.np = c->nfl[F_P];
+        a.nRrho = c->nfl[F_RRHO];
+        if (!c->dist && !partial) {
+            hipLaunchKernelGGL(k_commit, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, a, c->S);
             hipLaunchKernelGGL(k_commit_scalars, dim3(1), dim3(1), 0, c->stream, c->S);
         }
         HIPCHK(hipGetLastError());
         CHK(read_scalars(c));
+        if (c->dist) {
+            /* the ranks agree on the maxima, the sums and on whether to redo the step; the
+             * time step and the commit follow from the agreed values */
+            DevScalars& s = *c->S_host;
+            double vmax[4] = {s.maxmu, s.maxf, (double)s.violation, s.disp};
+            double vsum[3] = {s.errsum0, s.errsum, (double)s.hit_pairs};
+            CHK(allreduce_host(c, vmax, 4, 0));
+            CHK(allreduce_host(c, vsum, 3, 1));
+            hipLaunchKernelGGL(k_apply_global, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, vmax[0], vmax[1], vsum[0], vsum[1],
+                               vsum[2], vmax[2] != 0.0 ? 1 : 0, partial ? 0 : 1);
+            if (!partial) {
+                hipLaunchKernelGGL(k_commit, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, a, c->S);
+                hipLaunchKernelGGL(k_commit_scalars, dim3(1), dim3(1), 0, c->stream, c->S);
+            }
+            HIPCHK(hipGetLastError());
+            CHK(read_scalars(c));
+            c->S_host->disp = vmax[3];
+        }
         c->disp_host = c->S_host->disp;
         if (c->S_host->violation && mode < 2) {
             ++c->redos;
@@ -547,9 +853,9 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
 
 template <typename T>
 int put_component(sph_ctx* c, T* dst, size_t stride, const T* host) {
+    const uint32_t m = n_local(c);
     HIPCHK(hipMemcpyAsync(c->tmp, host, sizeof(T) * c->n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_put<T>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, dst, stride, (const T*)c->tmp,
-                       c->id, c->n);
+    hipLaunchKernelGGL(k_put<T>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, dst, stride, (const T*)c->tmp, c->id, m);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return SPH_OK;
@@ -557,8 +863,8 @@ int put_component(sph_ctx* c, T* dst, size_t stride, const T* host) {
 
 template <typename T>
 int get_component(sph_ctx* c, const T* src, size_t stride, T* host) {
-    hipLaunchKernelGGL(k_get<T>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, src, stride, (T*)c->tmp, c->id,
-                       c->n);
+    const uint32_t m = n_local(c);
+    hipLaunchKernelGGL(k_get<T>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, src, stride, (T*)c->tmp, c->id, m);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(host, c->tmp, sizeof(T) * c->n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -579,16 +885,28 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     sph_ctx* c = new sph_ctx();
     *out = c; /* returned even on failure so that the message can be read; destroy it either way */
     c->prm = *p;
+    memset(&c->tr, 0, sizeof c->tr);
     if (p->dim != 2 && p->dim != 3) return fail(c, SPH_EINVAL, "dim must be 2 or 3");
     if (p->variant != SPH_VARIANT_WCSPH && p->variant != SPH_VARIANT_WCXSPH)
         return fail(c, SPH_EINVAL, "unknown variant");
     if (p->variant == SPH_VARIANT_WCSPH && p->dim != 2)
         return fail(c, SPH_EINVAL, "the single-mass variant exists in 2-D only");
     if (p->npts == 0 || p->npts >= (1ull << 31)) return fail(c, SPH_EINVAL, "npts out of range");
-    if (p->bound_parts > p->npts) return fail(c, SPH_EINVAL, "bound_parts > npts");
+    c->dist = p->nranks > 1;
+    if (!c->dist && p->bound_parts > p->npts) return fail(c, SPH_EINVAL, "bound_parts > npts");
     if (!(p->H > 0) || !(p->search_radius_sq > 0) || !(p->rho0 > 0) || p->subits < 1 || p->subits > 64 ||
         p->g_axis < 0 || p->g_axis >= p->dim)
         return fail(c, SPH_EINVAL, "bad physical constants");
+    if (c->dist) {
+        if (p->rank < 0 || p->rank >= p->nranks) return fail(c, SPH_EINVAL, "rank out of range");
+        if (p->npts_global < p->npts || p->npts_global >= (1ull << 32)) return fail(c, SPH_EINVAL, "npts_global out of range");
+        if (p->capacity <= p->npts || p->capacity >= (1ull << 31)) return fail(c, SPH_EINVAL, "capacity must exceed npts (room for the halo)");
+        if (!(p->slab_hi > p->slab_lo)) return fail(c, SPH_EINVAL, "empty slab interval");
+        c->rank = p->rank;
+        c->nranks = p->nranks;
+        c->has_side[0] = p->rank > 0;
+        c->has_side[1] = p->rank < p->nranks - 1;
+    }
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -603,9 +921,9 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     c->dim = p->dim;
     c->xsph = p->variant == SPH_VARIANT_WCXSPH;
     c->n = (uint32_t)p->npts;
-    c->stride = (c->n + 63u) & ~63u;
-    c->nblocks = nblk(c->n);
-    c->npairblocks = ((c->n + PAIR_PARTICLES - 1) / PAIR_PARTICLES + 7u) & ~7u; /* a multiple of the XCD count */
+    c->cap = c->dist ? (uint32_t)p->capacity : c->n;
+    c->halo_cap = (c->cap - c->n) / 2;
+    c->npairblocks = pairblocks(c->n) + 24; /* up to three launches per sweep, each padded to 8 */
     if (p->skin_frac > 0) c->skin_frac = p->skin_frac;
     c->brick_log2 = c->dim == 3 ? 2u : 3u;
     if (const char* e = getenv("SPH_BRICK_LOG2")) c->brick_log2 = (uint32_t)std::min(5, std::max(0, atoi(e)));
@@ -638,9 +956,9 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     }
     d.mass = p->mass;
     d.hvisc = 0.01 * p->HSQ;
-    d.npts_d = 1.0 * (double)p->npts;
+    d.npts_d = 1.0 * (double)(c->dist ? p->npts_global : p->npts);
 
-    const size_t n = c->n;
+    const size_t n = c->cap;
     for (int q = 0; q < 4; ++q)
         for (int k = 0; k < c->dim; ++k) {
             CHK(dalloc(c, &c->nd[q * 3 + k], n));
@@ -657,6 +975,7 @@ int sph_create(const sph_params* p, sph_ctx** out) {
         HIPCHK(hipMemsetAsync(c->rec[b], 0, n * sizeof(Rec), c->stream));
     }
     CHK(dalloc(c, &c->rec_alt, n));
+    HIPCHK(hipMemsetAsync(c->rec_alt, 0, n * sizeof(Rec), c->stream));
     for (int q = 0; q < 2; ++q)
         for (int k = 0; k < c->dim; ++k) {
             CHK(dalloc(c, &c->pd[q * 3 + k], n));
@@ -671,7 +990,7 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     HIPCHK(hipMemsetAsync(c->pp, 0, n * sizeof(float), c->stream));
     CHK(dalloc(c, &c->id, n));
     CHK(dalloc(c, &c->id_alt, n));
-    hipLaunchKernelGGL(k_iota, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, c->id, c->n);
+    hipLaunchKernelGGL(k_iota, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, c->id, c->n);
     CHK(dalloc(c, &c->keys, n));
     CHK(dalloc(c, &c->keys_alt, n));
     CHK(dalloc(c, &c->perm, n));
@@ -681,17 +1000,38 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     CHK(dalloc(c, &c->cend, c->cell_cap));
     c->cap_k = p->max_neighbours > 0 ? (uint32_t)p->max_neighbours : (c->dim == 3 ? 96u : 40u);
     c->cap_k = (c->cap_k + 3u) & ~3u;
-    CHK(dalloc(c, &c->nbr, (size_t)c->cap_k * c->stride));
+    CHK(dalloc(c, &c->nbr, (size_t)c->cap_k * c->n));
     CHK(dalloc(c, &c->cnt, n));
-    CHK(dalloc(c, &c->need, 1));
+    CHK(dalloc(c, &c->need, 8));
     CHK(dalloc(c, &c->S, 1));
     HIPCHK(hipHostMalloc((void**)&c->S_host, sizeof(DevScalars)));
     HIPCHK(hipHostMalloc((void**)&c->bbox_host, sizeof(double) * 6 * BBOX_BLOCKS));
-    HIPCHK(hipHostMalloc((void**)&c->need_host, sizeof(uint32_t)));
+    HIPCHK(hipHostMalloc((void**)&c->need_host, 8 * sizeof(uint32_t)));
     CHK(dalloc(c, &c->part, (size_t)PART_FIELDS * c->npairblocks));
     CHK(dalloc(c, &c->part2, (size_t)PART_FIELDS * PART_GROUPS));
     CHK(dalloc(c, &c->bbox_part, (size_t)6 * BBOX_BLOCKS));
     HIPCHK(hipMalloc(&c->tmp, n * 8));
+    if (c->dist) {
+        const size_t hc = c->halo_cap;
+        CHK(dalloc(c, &c->gid, n));
+        CHK(dalloc(c, &c->gid_alt, n));
+        CHK(dalloc(c, &c->hbeg, c->cell_cap));
+        CHK(dalloc(c, &c->hend, c->cell_cap));
+        CHK(dalloc(c, &c->send_idx, 2 * hc));
+        CHK(dalloc(c, &c->halo_pos, 2 * hc));
+        CHK(dalloc(c, &c->sendbuf, 2 * hc));
+        CHK(dalloc(c, &c->recvbuf, 2 * hc));
+        CHK(dalloc(c, &c->sendgid, 2 * hc));
+        CHK(dalloc(c, &c->recvgid, 2 * hc));
+        CHK(dalloc(c, &c->flags, n));
+        CHK(dalloc(c, &c->fpos, n));
+        CHK(dalloc(c, &c->red_dev, 64 + 2 * (size_t)c->nranks));
+        HIPCHK(hipHostMalloc((void**)&c->h_send, 2 * hc * sizeof(Rec) + 64));
+        HIPCHK(hipHostMalloc((void**)&c->h_recv, 2 * hc * sizeof(Rec) + 64));
+        HIPCHK(hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_recvd, hipEventDisableTiming));
+    }
 
     memset(c->S_host, 0, sizeof(DevScalars));
     c->S_host->dt = p->dt0;
@@ -704,6 +1044,8 @@ int sph_create(const sph_params* p, sph_ctx** out) {
 void sph_destroy(sph_ctx* c) {
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)hipStreamSynchronize(c->comm);
+    if (c->rccl && c->rccl_free) c->rccl_free(c->rccl);
     for (int q = 0; q < 12; ++q) {
         if (c->nd[q]) (void)hipFree(c->nd[q]);
         if (c->nd_alt[q]) (void)hipFree(c->nd_alt[q]);
@@ -719,18 +1061,40 @@ void sph_destroy(sph_ctx* c) {
         if (c->pd[q]) (void)hipFree(c->pd[q]);
         if (c->pd_alt[q]) (void)hipFree(c->pd_alt[q]);
     }
-    void* ptrs[] = {c->pp, c->pp_alt, c->pRrho, c->pRrho_alt, c->id,   c->id_alt, c->keys, c->keys_alt, c->perm,     c->perm_alt,
-                    c->hist,  c->bsum,      c->cbeg, c->cend,   c->nbr,  c->cnt,      c->need,     c->S,
-                    c->part, c->part2, c->bbox_part, c->tmp};
+    void* ptrs[] = {c->pp,   c->pp_alt, c->pRrho, c->pRrho_alt, c->id,       c->id_alt,   c->gid,     c->gid_alt, c->keys,
+                    c->keys_alt, c->perm, c->perm_alt, c->hist, c->bsum,     c->cbeg,     c->cend,    c->hbeg,    c->hend,
+                    c->nbr,  c->cnt,    c->need,  c->S,         c->part,     c->part2,    c->bbox_part, c->tmp,   c->send_idx,
+                    c->halo_pos, c->sendbuf, c->recvbuf, c->sendgid, c->recvgid, c->flags, c->fpos,   c->red_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->S_host) (void)hipHostFree(c->S_host);
     if (c->bbox_host) (void)hipHostFree(c->bbox_host);
     if (c->need_host) (void)hipHostFree(c->need_host);
+    if (c->h_send) (void)hipHostFree(c->h_send);
+    if (c->h_recv) (void)hipHostFree(c->h_recv);
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : c->rb_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
+    if (c->ev_recvd) (void)hipEventDestroy(c->ev_recvd);
+    if (c->comm) (void)hipStreamDestroy(c->comm);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int sph_set_transport(sph_ctx* c, const sph_transport* t) {
+    if (!c || !t || !t->sendrecv || !t->allreduce) return SPH_EINVAL;
+    if (!c->dist) return fail(c, SPH_ESTATE, "a transport is only used when nranks > 1");
+    c->tr = *t;
+    c->have_tr = true;
+    return SPH_OK;
+}
+
+int sph_upload_global_ids(sph_ctx* c, const uint32_t* gids) {
+    if (!c || !gids) return SPH_EINVAL;
+    if (!c->dist) return fail(c, SPH_ESTATE, "global ids are only used when nranks > 1");
+    HIPCHK(hipSetDevice(c->device));
+    c->list_valid = false;
+    return put_component<uint32_t>(c, c->gid, 1, gids);
 }
 
 int sph_upload(sph_ctx* c, int32_t which, const sph_fields* s) {
@@ -754,10 +1118,7 @@ int sph_upload(sph_ctx* c, int32_t which, const sph_fields* s) {
     } else {
         Rec* r = c->rec[c->b0];
         for (int d = 0; d < dim; ++d) {
-            if (s->x[d]) {
-                CHK(put_component<double>(c, &r->xv[d][0], 8, s->x[d]));
-                c->list_valid = false;
-            }
+            if (s->x[d]) CHK(put_component<double>(c, &r->xv[d][0], 8, s->x[d]));
             if (s->v[d]) CHK(put_component<double>(c, &r->xv[d][1], 8, s->v[d]));
             if (s->f[d]) CHK(put_component<double>(c, c->pd[d], 1, s->f[d]));
             if (s->V[d] && c->xsph) CHK(put_component<double>(c, c->pd[3 + d], 1, s->V[d]));
@@ -767,7 +1128,7 @@ int sph_upload(sph_ctx* c, int32_t which, const sph_fields* s) {
         if (s->m) CHK(put_component<float>(c, &r->m, 16, s->m));
         if (s->Rrho) CHK(put_component<float>(c, c->pRrho, 1, s->Rrho));
         if (s->rho || s->p) {
-            hipLaunchKernelGGL(k_fix_prr, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, r, c->pp, c->n);
+            hipLaunchKernelGGL(k_fix_prr, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, c->pp, c->n);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(c->stream));
         }
@@ -819,18 +1180,22 @@ int sph_forces(sph_ctx* c, int32_t which) {
         CHK(pack_n_into(c, c->rec[src]));
     }
     CHK(rebuild(c, src));
-    if (which == SPH_STATE_N) {
-        /* rebuild moved the scratch buffer; find it again: it is the one that is neither b0 nor free */
-        src = (c->b0 + 1) % NREC;
-        /* lists were built for state n's positions; state n+1 may differ */
-        c->list_valid = false;
-    }
+    /* lists built for state n's positions do not serve state n+1 */
+    if (which == SPH_STATE_N) c->list_valid = false;
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, c->stream, c->S);
-    CHK(launch_pair<false>(c, c->rec[src], nullptr, out_state(c, which), 1, 0));
-    hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS), dim3(SPH_BLOCK), 0, c->stream, c->part, c->npairblocks, 1, c->part2);
+    const uint32_t part_n = pairblocks(c->n);
+    CHK(launch_pair<false>(c, c->rec[src], nullptr, out_state(c, which), 1, 0, 0, c->n, 0, part_n));
+    hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS), dim3(SPH_BLOCK), 0, c->stream, c->part, part_n, 1, c->part2);
     hipLaunchKernelGGL(k_forces_finalize, dim3(1), dim3(1), 0, c->stream, c->S, c->part2);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->dist) {
+        CHK(read_scalars(c));
+        double v[1] = {c->S_host->maxmu};
+        CHK(allreduce_host(c, v, 1, 0));
+        HIPCHK(hipMemcpyAsync(&c->S->maxmu, v, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     return SPH_OK;
 }
 
@@ -839,8 +1204,8 @@ int sph_zero_boundary_forces(sph_ctx* c, int32_t which) {
     if (which != SPH_STATE_N && which != SPH_STATE_NP1) return fail(c, SPH_EINVAL, "bad state selector");
     HIPCHK(hipSetDevice(c->device));
     OutState o = out_state(c, which);
-    hipLaunchKernelGGL(k_zero_wall_f, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, o.f[0], o.f[1], o.f[2], c->dim,
-                       c->id, c->n, c->dp.bound_parts);
+    hipLaunchKernelGGL(k_zero_wall_f, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, o.f[0], o.f[1], o.f[2], c->dim,
+                       wall_ids(c), c->n, c->dp.bound_parts);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return SPH_OK;
@@ -898,18 +1263,15 @@ int sph_neighbours(sph_ctx* c, int32_t which, uint64_t* row_offsets, uint32_t* c
         CHK(pack_n_into(c, c->rec[src]));
     }
     CHK(rebuild(c, src));
-    if (which == SPH_STATE_N) {
-        src = (c->b0 + 1) % NREC;
-        c->list_valid = false;
-    }
+    if (which == SPH_STATE_N) c->list_valid = false;
     const uint32_t n = c->n;
     uint32_t* counts = (uint32_t*)c->tmp;
     if (c->dim == 3)
-        hipLaunchKernelGGL(k_nbr_count<3>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], c->nbr,
-                           c->cap_k, c->cnt, c->id, counts);
+        hipLaunchKernelGGL(k_nbr_count<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], c->nbr, c->cap_k,
+                           c->cnt, c->id, counts);
     else
-        hipLaunchKernelGGL(k_nbr_count<2>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], c->nbr,
-                           c->cap_k, c->cnt, c->id, counts);
+        hipLaunchKernelGGL(k_nbr_count<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], c->nbr, c->cap_k,
+                           c->cnt, c->id, counts);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> hc(n);
     HIPCHK(hipMemcpyAsync(hc.data(), counts, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
@@ -929,15 +1291,16 @@ int sph_neighbours(sph_ctx* c, int32_t which, uint64_t* row_offsets, uint32_t* c
         return fail(c, SPH_ENOMEM, "no device memory for the neighbour table");
     }
     int rc = SPH_OK;
+    const uint32_t* colid = c->dist ? c->gid : c->id; /* slab runs report global indices */
     do {
         if (hipMemcpyAsync(doffs, row_offsets, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream) !=
             hipSuccess) { rc = SPH_EDEVICE; break; }
         if (c->dim == 3)
-            hipLaunchKernelGGL(k_nbr_fill<3>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src],
-                               c->nbr, c->cap_k, c->cnt, c->id, doffs, dcols);
+            hipLaunchKernelGGL(k_nbr_fill<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], c->nbr,
+                               c->cap_k, c->cnt, c->id, colid, doffs, dcols);
         else
-            hipLaunchKernelGGL(k_nbr_fill<2>, dim3(c->nblocks), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src],
-                               c->nbr, c->cap_k, c->cnt, c->id, doffs, dcols);
+            hipLaunchKernelGGL(k_nbr_fill<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], c->nbr,
+                               c->cap_k, c->cnt, c->id, colid, doffs, dcols);
         if (hipGetLastError() != hipSuccess) { rc = SPH_EDEVICE; break; }
         if (hipMemcpyAsync(cols, dcols, sizeof(uint32_t) * off, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
             rc = SPH_EDEVICE;
@@ -979,6 +1342,112 @@ int sph_profile_read(sph_ctx* c, double* pair_ms, uint64_t* pair_launches, doubl
     if (rebuild_ms) *rebuild_ms = tot;
     if (rebuilds) *rebuilds = c->rb_used;
     c->rb_used = 0;
+    return SPH_OK;
+}
+
+/* ---- built-in transport over RCCL -------------------------------------------------------
+ * The library is opened at run time, so that a process which already carries an RCCL (one
+ * that imported torch, say) shares that copy, and single-GPU users need none. */
+struct RcclState {
+    void* lib = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+};
+
+static void* rccl_open() {
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    return lib;
+}
+
+static int rccl_sendrecv(void* user, const void* sL, uint64_t nsL, void* rL, uint64_t nrL, const void* sR, uint64_t nsR,
+                         void* rR, uint64_t nrR, void* stream) {
+    RcclState* r = (RcclState*)user;
+    hipStream_t st = (hipStream_t)stream;
+    if (!(nsL || nrL || nsR || nrR)) return 0;
+    bool ok = r->GroupStart() == ncclSuccess;
+    if (nsL) ok = ok && r->Send(sL, nsL, ncclUint8, r->rank - 1, r->comm, st) == ncclSuccess;
+    if (nrL) ok = ok && r->Recv(rL, nrL, ncclUint8, r->rank - 1, r->comm, st) == ncclSuccess;
+    if (nsR) ok = ok && r->Send(sR, nsR, ncclUint8, r->rank + 1, r->comm, st) == ncclSuccess;
+    if (nrR) ok = ok && r->Recv(rR, nrR, ncclUint8, r->rank + 1, r->comm, st) == ncclSuccess;
+    ok = (r->GroupEnd() == ncclSuccess) && ok;
+    return ok ? 0 : 1;
+}
+
+static int rccl_allreduce(void* user, double* vals, int32_t n, int32_t op, void* stream) {
+    RcclState* r = (RcclState*)user;
+    return r->AllReduce(vals, vals, (size_t)n, ncclDouble, op ? ncclSum : ncclMax, r->comm, (hipStream_t)stream) == ncclSuccess
+               ? 0
+               : 1;
+}
+
+static void rccl_release(void* p) {
+    RcclState* r = (RcclState*)p;
+    if (r->comm && r->CommDestroy) (void)r->CommDestroy(r->comm);
+    delete r; /* the library handle stays open: other users in the process may share it */
+}
+
+int sph_rccl_unique_id(void* unique_id_128) {
+    if (!unique_id_128) return SPH_EINVAL;
+    void* lib = rccl_open();
+    if (!lib) return SPH_ECOMM;
+    auto get = (ncclResult_t(*)(ncclUniqueId*))dlsym(lib, "ncclGetUniqueId");
+    if (!get) return SPH_ECOMM;
+    ncclUniqueId id;
+    if (get(&id) != ncclSuccess) return SPH_ECOMM;
+    memcpy(unique_id_128, &id, sizeof id);
+    return SPH_OK;
+}
+
+int sph_use_rccl(sph_ctx* c, const void* unique_id_128) {
+    if (!c || !unique_id_128) return SPH_EINVAL;
+    if (!c->dist) return fail(c, SPH_ESTATE, "a transport is only used when nranks > 1");
+    if (c->rccl) return fail(c, SPH_ESTATE, "the RCCL transport is already installed");
+    HIPCHK(hipSetDevice(c->device));
+    RcclState* r = new RcclState();
+    r->lib = rccl_open();
+    if (!r->lib) {
+        delete r;
+        return fail(c, SPH_ECOMM, "librccl.so.1 could not be opened");
+    }
+#define SYM(field, name)                                                  \
+    r->field = (decltype(r->field))dlsym(r->lib, name);                   \
+    if (!r->field) {                                                      \
+        delete r;                                                         \
+        return fail(c, SPH_ECOMM, "RCCL lacks " name);                    \
+    }
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(Send, "ncclSend")
+    SYM(Recv, "ncclRecv")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+#undef SYM
+    r->rank = c->rank;
+    r->nranks = c->nranks;
+    ncclUniqueId id;
+    memcpy(&id, unique_id_128, sizeof id);
+    if (r->CommInitRank(&r->comm, c->nranks, id, c->rank) != ncclSuccess) {
+        delete r;
+        return fail(c, SPH_ECOMM, "ncclCommInitRank failed");
+    }
+    c->rccl = r;
+    c->rccl_free = rccl_release;
+    sph_transport t;
+    t.user = r;
+    t.host_buffers = 0;
+    t.sendrecv = rccl_sendrecv;
+    t.allreduce = rccl_allreduce;
+    c->tr = t;
+    c->have_tr = true;
     return SPH_OK;
 }
 

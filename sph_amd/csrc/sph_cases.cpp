@@ -206,4 +206,54 @@ int sph_case_init(const sph_case* c, const sph_fields* dst) {
     return i == p.npts ? SPH_OK : SPH_EINVAL;
 }
 
+int sph_case_init_range(const sph_case* c, double xlo, double xhi, const sph_fields* dst, uint32_t* gids,
+                        uint64_t* count) {
+    if (!c || !count) return SPH_EINVAL;
+    sph_params p;
+    double simmass, boundmass;
+    const int rc = sph_case_params(c, &p, &simmass, &boundmass);
+    if (rc != SPH_OK) return rc;
+    if (p.npts >= (1ull << 32)) return SPH_EINVAL;
+    const int dim = p.dim;
+    const float rho = (float)p.rho0;
+    const float wall_m = (float)boundmass, fluid_m = (float)simmass;
+    uint64_t i = 0, g = 0;
+    visit_particles(c, [&](const double* x, bool wall) {
+        const uint64_t gi = g++;
+        if (!(x[0] >= xlo && x[0] < xhi)) return;
+        if (dst) {
+            for (int d = 0; d < dim; ++d) {
+                if (dst->x[d]) dst->x[d][i] = x[d];
+                if (dst->v[d]) dst->v[d][i] = 0.0;
+                if (dst->V[d]) dst->V[d][i] = 0.0;
+                if (dst->f[d]) dst->f[d][i] = 0.0;
+            }
+            if (dst->rho) dst->rho[i] = rho;
+            if (dst->p) dst->p[i] = 0.0f;
+            if (dst->Rrho) dst->Rrho[i] = 0.0f;
+            if (dst->m) dst->m[i] = wall ? wall_m : fluid_m;
+        }
+        if (gids) gids[i] = (uint32_t)gi;
+        ++i;
+    });
+    *count = i;
+    return SPH_OK;
+}
+
+int sph_case_histogram_x(const sph_case* c, int32_t nbins, uint64_t* fluid_counts, uint64_t* wall_counts) {
+    if (!c || nbins < 1 || !fluid_counts || !wall_counts) return SPH_EINVAL;
+    sph_params p;
+    const int rc = sph_case_params(c, &p, nullptr, nullptr);
+    if (rc != SPH_OK) return rc;
+    for (int b = 0; b < nbins; ++b) fluid_counts[b] = wall_counts[b] = 0;
+    const double scale = nbins / c->box[0];
+    visit_particles(c, [&](const double* x, bool wall) {
+        double b = floor(x[0] * scale);
+        if (!(b >= 0)) b = 0;
+        if (b > nbins - 1) b = nbins - 1;
+        (wall ? wall_counts : fluid_counts)[(int)b] += 1;
+    });
+    return SPH_OK;
+}
+
 }  /* extern "C" */

@@ -10,6 +10,7 @@
 #include "sph_types.h"
 
 #define SPH_BLOCK 256
+#define SPH_HALO_ID 0xFFFFFFFFu /* id[] of a particle owned by a neighbouring slab */
 
 /* ------------------------------------------------------------------------------------------ */
 /* small helpers                                                                              */
@@ -312,6 +313,8 @@ struct ReorderArgs {
     Rec* rd[2];
     const uint32_t* ids;
     uint32_t* idd;
+    const uint32_t* gids; /* global ids (slab runs), may be null */
+    uint32_t* gidd;
 };
 
 __global__ __launch_bounds__(SPH_BLOCK) void k_reorder(ReorderArgs a) {
@@ -322,18 +325,20 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reorder(ReorderArgs a) {
     for (int k = 0; k < a.nf; ++k) a.df[k][i] = a.sf[k][s];
     for (int k = 0; k < a.nr; ++k) a.rd[k][i] = a.rs[k][s];
     a.idd[i] = a.ids[s];
+    if (a.gids) a.gidd[i] = a.gids[s];
 }
 
 /* ------------------------------------------------------------------------------------------ */
 /* cell table: first and one-past-last sorted position of every non-empty cell                */
 
 __global__ __launch_bounds__(SPH_BLOCK) void k_cell_mark(const uint32_t* __restrict__ keys, uint32_t n,
-                                                         uint32_t* __restrict__ cbeg, uint32_t* __restrict__ cend) {
+                                                         uint32_t index_base, uint32_t* __restrict__ cbeg,
+                                                         uint32_t* __restrict__ cend) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = keys[i];
-    if (i == 0 || keys[i - 1] != k) cbeg[k] = i;
-    if (i == n - 1 || keys[i + 1] != k) cend[k] = i + 1;
+    if (i == 0 || keys[i - 1] != k) cbeg[k] = index_base + i;
+    if (i == n - 1 || keys[i + 1] != k) cend[k] = index_base + i + 1;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -376,7 +381,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
                                                           const uint32_t* __restrict__ cend, double rl2,
                                                           uint32_t* __restrict__ nbr, uint32_t stride, uint32_t cap,
                                                           uint32_t* __restrict__ cnt, uint32_t* __restrict__ need,
-                                                          const uint32_t* __restrict__ id, uint32_t wall_below) {
+                                                          const uint32_t* __restrict__ id, uint32_t wall_below,
+                                                          const uint32_t* __restrict__ hbeg,
+                                                          const uint32_t* __restrict__ hend) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= n) return;
     /* wall_below > 0: pairs of two wall particles are left out (see k_walls_at_rest) */
@@ -396,16 +403,20 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
                 const int az = cz + dz;
                 if (DIM == 3 && (az < 0 || az >= g.n[2])) continue;
                 const uint32_t c = cell_key<DIM>(g, ax, ay, az);
-                const uint32_t b = cbeg[c], e = cend[c]; /* empty cell: b = 0xFFFFFFFF, e = 0 */
-                for (uint32_t j = b; j < e; ++j) {
-                    if (j == i) continue;
-                    if (i_wall && id[j] < wall_below) continue;
-                    const double dx_ = xi - rec[j].xv[0][0], dy_ = yi - rec[j].xv[1][0];
-                    const double dz_ = DIM == 3 ? zi - rec[j].xv[2][0] : 0.0;
-                    const double d2 = dist2_exact(dx_, dy_, dz_);
-                    if (d2 <= rl2) {
-                        if (k < cap) nbr[(size_t)i * stride + k] = j;
-                        ++k;
+                /* own particles of the cell, then (slab runs) the neighbours' particles in it */
+                for (int part = 0; part < (hbeg ? 2 : 1); ++part) {
+                    const uint32_t b = part ? hbeg[c] : cbeg[c]; /* empty cell: b = 0xFFFFFFFF, e = 0 */
+                    const uint32_t e = part ? hend[c] : cend[c];
+                    for (uint32_t j = b; j < e; ++j) {
+                        if (j == i) continue;
+                        if (i_wall && id[j] < wall_below) continue;
+                        const double dx_ = xi - rec[j].xv[0][0], dy_ = yi - rec[j].xv[1][0];
+                        const double dz_ = DIM == 3 ? zi - rec[j].xv[2][0] : 0.0;
+                        const double d2 = dist2_exact(dx_, dy_, dz_);
+                        if (d2 <= rl2) {
+                            if (k < cap) nbr[(size_t)i * stride + k] = j;
+                            ++k;
+                        }
                     }
                 }
             }
@@ -520,7 +531,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
                                                     const uint32_t* __restrict__ cnt, OutState out, int store_out,
                                                     int zero_wall, NState ns, const uint32_t* __restrict__ id,
                                                     Rec* __restrict__ rout, float* __restrict__ pout,
-                                                    DevScalars* __restrict__ S, double* __restrict__ part, int dbg) {
+                                                    DevScalars* __restrict__ S, double* __restrict__ part, int dbg,
+                                                    uint32_t first, uint32_t count, uint32_t part_base,
+                                                    uint32_t part_n) {
     __shared__ __attribute__((aligned(16))) char stage[(SPH_BLOCK / 64) * PAIR_LDS_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane & 3;
@@ -530,9 +543,11 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
      * (Placement only changes speed, never results.) */
     const uint32_t per_xcd = gridDim.x >> 3; /* the grid is a multiple of 8 */
     const uint32_t block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    const uint32_t i_raw = block * PAIR_PARTICLES + (threadIdx.x >> 2);
-    const bool active = i_raw < P.n;
-    const uint32_t i = active ? i_raw : P.n - 1;
+    /* this launch covers particles [first, first+count) (a slab run launches its boundary
+     * layers and its interior separately) */
+    const uint32_t i_raw = first + block * PAIR_PARTICLES + (threadIdx.x >> 2);
+    const bool active = i_raw < first + count;
+    const uint32_t i = active ? i_raw : first + count - 1;
     char* const wstage = stage + wave * PAIR_LDS_WAVE;
 
     const Rec ri = rin[i];
@@ -773,7 +788,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
     if (threadIdx.x == 0) {
         double a = red[0][0];
         for (int w = 1; w < SPH_BLOCK / 64; ++w) a = fmax(a, red[w][0]);
-        const uint32_t nb = gridDim.x;
+        const uint32_t nb = part_n;
+        part += part_base;
         part[block] = a;
         if (FUSED) {
             double b = red[0][1], c2 = red[0][2], s = red[0][3], h = red[0][4];
@@ -845,7 +861,10 @@ __global__ void k_sweep_finalize(DevParams P, DevScalars* S, const double* __res
     const double errsum = fold_groups(part2, 3);
     S->hit_pairs = (unsigned long long)fold_groups(part2, 4);
     S->errsum = errsum;
-    if (k == 0) S->logbase = log10(sqrt(errsum / P.npts_d));
+    if (k == 0) {
+        S->errsum0 = errsum;
+        S->logbase = log10(sqrt(errsum / P.npts_d));
+    }
     S->maxmu = maxmu;
     S->disp += sqrt(move2);
     /* the positions just written feed the next sweep's pair loop through lists built earlier:
@@ -942,13 +961,13 @@ template <typename T>
 __global__ __launch_bounds__(SPH_BLOCK) void k_put(T* __restrict__ dst, size_t stride, const T* __restrict__ src_orig,
                                                    const uint32_t* __restrict__ id, uint32_t n) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
-    if (i < n) dst[(size_t)i * stride] = src_orig[id[i]];
+    if (i < n && id[i] != SPH_HALO_ID) dst[(size_t)i * stride] = src_orig[id[i]];
 }
 template <typename T>
 __global__ __launch_bounds__(SPH_BLOCK) void k_get(const T* __restrict__ src, size_t stride, T* __restrict__ dst_orig,
                                                    const uint32_t* __restrict__ id, uint32_t n) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
-    if (i < n) dst_orig[id[i]] = src[(size_t)i * stride];
+    if (i < n && id[i] != SPH_HALO_ID) dst_orig[id[i]] = src[(size_t)i * stride];
 }
 template <typename T>
 __global__ __launch_bounds__(SPH_BLOCK) void k_fill(T* __restrict__ dst, T v, uint32_t n) {
@@ -969,6 +988,86 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_zero_wall_f(double* f0, double* f
     f0[i] = 0.0;
     f1[i] = 0.0;
     if (dim == 3) f2[i] = 0.0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* slab decomposition: halo selection, packing, placing                                       */
+
+/* flags[i] = 1 if owned particle i is needed by the left neighbour (side 0: x <= thr) or by
+ * the right neighbour (side 1: x >= thr) */
+__global__ __launch_bounds__(SPH_BLOCK) void k_flag_halo(const Rec* __restrict__ rec, uint32_t n, int side, double thr,
+                                                         uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double x = rec[i].xv[0][0];
+    flags[i] = side == 0 ? (x <= thr ? 1u : 0u) : (x >= thr ? 1u : 0u);
+}
+/* pos = exclusive scan of flags: out[pos[i]] = i for flagged i (ascending); entries beyond
+ * `limit` are dropped (the host sees the count and reports the overflow) */
+__global__ __launch_bounds__(SPH_BLOCK) void k_compact(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
+                                                       uint32_t n, uint32_t limit, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i < n && flags[i] && pos[i] < limit) out[pos[i]] = i;
+}
+__global__ __launch_bounds__(SPH_BLOCK) void k_gather_rec(const Rec* __restrict__ rec, const uint32_t* __restrict__ idx,
+                                                          uint32_t m, Rec* __restrict__ out) {
+    const uint32_t k = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (k < m) out[k] = rec[idx[k]];
+}
+__global__ __launch_bounds__(SPH_BLOCK) void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx,
+                                                          uint32_t m, uint32_t* __restrict__ out) {
+    const uint32_t k = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (k < m) out[k] = src[idx[k]];
+}
+/* received record k goes to position pos[k] (pos == nullptr: base + k) */
+__global__ __launch_bounds__(SPH_BLOCK) void k_scatter_rec(const Rec* __restrict__ in, const uint32_t* __restrict__ pos,
+                                                           uint32_t base, uint32_t m, Rec* __restrict__ rec) {
+    const uint32_t k = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (k < m) rec[pos ? pos[k] : base + k] = in[k];
+}
+/* after the halo region was sorted: where did the k-th received particle go */
+__global__ __launch_bounds__(SPH_BLOCK) void k_halo_pos(const uint32_t* __restrict__ perm, uint32_t m, uint32_t base,
+                                                        uint32_t* __restrict__ pos) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i < m) pos[perm[i]] = base + i;
+}
+/* sorted halo region: records and global ids gathered through the sort permutation */
+__global__ __launch_bounds__(SPH_BLOCK) void k_reorder_halo(const uint32_t* __restrict__ perm, uint32_t m,
+                                                            const Rec* __restrict__ rs, Rec* __restrict__ rd,
+                                                            const uint32_t* __restrict__ gs, uint32_t* __restrict__ gd) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    rd[i] = rs[perm[i]];
+    gd[i] = gs[perm[i]];
+}
+/* first sorted position whose key is >= bound[q], q = 0, 1 */
+__global__ void k_lower_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint32_t b0, uint32_t b1,
+                               uint32_t* __restrict__ out) {
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t b = q ? b1 : b0;
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (keys[mid] < b) lo = mid + 1; else hi = mid;
+        }
+        out[q] = lo;
+    }
+}
+/* the step's scalars once every rank's values are folded: the same arithmetic as the last
+ * k_sweep_finalize, on global maxima and sums (WCXSPH3D.cpp:280-288, 293-298) */
+__global__ void k_apply_global(DevParams P, DevScalars* S, double maxmu, double maxf, double errsum0, double errsum,
+                               double hits, int violation, int full_step) {
+    S->maxmu = maxmu;
+    S->errsum = errsum;
+    S->logbase = log10(sqrt(errsum0 / P.npts_d));
+    S->hit_pairs = (unsigned long long)hits;
+    S->violation = violation;
+    if (full_step) {
+        S->maxf = maxf;
+        const double dtf = sqrt(P.H / maxf);
+        const double dtcv = P.H / (P.Cs + maxmu);
+        S->dt_next = 0.3 * fmin(dtf, dtcv);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -996,6 +1095,7 @@ template <int DIM>
 __global__ __launch_bounds__(SPH_BLOCK) void k_nbr_fill(DevParams P, const Rec* __restrict__ rec,
                                                         const uint32_t* __restrict__ nbr, uint32_t stride,
                                                         const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
+                                                        const uint32_t* __restrict__ colid,
                                                         const uint64_t* __restrict__ offs, uint32_t* __restrict__ cols) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= P.n) return;
@@ -1010,12 +1110,12 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_nbr_fill(DevParams P, const Rec* 
         }
         row[p] = v;
     };
-    if (dist2_exact(0.0, 0.0, 0.0) < P.R2) insert(id[i]);
+    if (dist2_exact(0.0, 0.0, 0.0) < P.R2) insert(colid[i]);
     const uint32_t c = cnt[i];
     for (uint32_t k = 0; k < c; ++k) {
         const uint32_t j = nbr[(size_t)i * stride + k];
         const double d2 = dist2_exact(rec[j].xv[0][0] - xi, rec[j].xv[1][0] - yi, DIM == 3 ? rec[j].xv[2][0] - zi : 0.0);
-        if (d2 < P.R2) insert(id[j]);
+        if (d2 < P.R2) insert(colid[j]);
     }
 }
 

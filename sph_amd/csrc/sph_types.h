@@ -47,6 +47,7 @@ struct DevScalars {
     double dt;        /* time step in use */
     double dt_next;   /* set by the last sweep, adopted at commit */
     double maxmu, maxf, errsum, logbase;
+    double errsum0;   /* errsum of the step's first sweep (the logbase numerator) */
     double disp;      /* upper bound of any particle's travel since the candidate lists were built */
     double disp_limit;
     float  t;

@@ -1,0 +1,223 @@
+"""Slab decomposition along x: one process and one context per GPU.
+
+The reference is one process on one core and has nothing like this.  Each rank owns the
+particles whose x lay in its interval at set-up; the library fetches the neighbouring slabs'
+boundary particles (the halo) before every Forces evaluation, and the ranks agree once per
+step on max(mu), max|f|, the convergence sums and on whether the step must be redone.
+
+Two transports move the bytes:
+  * the library's own RCCL transport (`Sim.use_rccl`), device buffers, for real multi-GPU runs;
+  * `HostTransport` below, host buffers over a torch.distributed process group (gloo), used
+    by the tests and wherever ranks share one GPU.
+"""
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+
+from . import capi
+
+
+# ---------------------------------------------------------------------------------------------
+# choosing the planes
+
+
+def choose_planes(case, nranks, wall_weight=0.4, nbins=16384):
+    """x-planes p[0] < ... < p[nranks] with p[0] = -inf, p[nranks] = +inf such that the slabs
+    carry about equal work.  A wall particle costs `wall_weight` of a fluid particle (pairs of
+    two resting wall particles are never evaluated)."""
+    if nranks == 1:
+        return [-np.inf, np.inf]
+    fl, wl = capi.case_histogram_x(case, nbins)
+    w = fl.astype(np.float64) + wall_weight * wl.astype(np.float64)
+    cum = np.cumsum(w)
+    edges = np.linspace(0.0, case.box[0], nbins + 1)
+    planes = [-np.inf]
+    for r in range(1, nranks):
+        target = cum[-1] * r / nranks
+        b = int(np.searchsorted(cum, target))
+        planes.append(float(edges[min(b + 1, nbins)]))
+    planes.append(np.inf)
+    for a, b in zip(planes[:-1], planes[1:]):
+        if not b > a:
+            raise capi.SphError("cannot cut %d slabs out of this case" % nranks)
+    return planes
+
+
+# ---------------------------------------------------------------------------------------------
+# host-buffer transport over a torch.distributed group
+
+
+def _view(ptr, nbytes):
+    import torch
+    buf = (C.c_ubyte * nbytes).from_address(ptr)
+    return torch.frombuffer(buf, dtype=torch.uint8)
+
+
+class HostTransport:
+    """sendrecv / allreduce callbacks on host memory through torch.distributed (any backend
+    that takes CPU tensors; gloo in practice)."""
+
+    def __init__(self, rank, nranks, group=None):
+        import torch.distributed as dist
+        self.dist, self.rank, self.nranks, self.group = dist, rank, nranks, group
+        self.error = None
+        self._sr = capi.SENDRECV_FN(self._sendrecv)
+        self._ar = capi.ALLREDUCE_FN(self._allreduce)
+        self.struct = capi.Transport(None, 1, self._sr, self._ar)
+
+    def _sendrecv(self, user, sL, nsL, rL, nrL, sR, nsR, rR, nrR, stream):
+        try:
+            d, ops = self.dist, []
+            if nsL:
+                ops.append(d.P2POp(d.isend, _view(sL, nsL), self.rank - 1, self.group))
+            if nsR:
+                ops.append(d.P2POp(d.isend, _view(sR, nsR), self.rank + 1, self.group))
+            if nrL:
+                ops.append(d.P2POp(d.irecv, _view(rL, nrL), self.rank - 1, self.group))
+            if nrR:
+                ops.append(d.P2POp(d.irecv, _view(rR, nrR), self.rank + 1, self.group))
+            if ops:
+                for w in d.batch_isend_irecv(ops):
+                    w.wait()
+            return 0
+        except Exception as e:  # a callback must not raise into C
+            self.error = e
+            return 1
+
+    def _allreduce(self, user, vals, n, op, stream):
+        try:
+            import torch
+            d = self.dist
+            buf = (C.c_double * n).from_address(C.addressof(vals.contents))
+            t = torch.frombuffer(buf, dtype=torch.float64)
+            d.all_reduce(t, op=d.ReduceOp.SUM if op else d.ReduceOp.MAX, group=self.group)
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
+
+
+# ---------------------------------------------------------------------------------------------
+
+
+class SlabSim(capi.Sim):
+    """This rank's slab of a case.  Every method that evaluates forces, steps or probes the
+    neighbour sets is collective: all ranks call it, in the same order."""
+
+    @classmethod
+    def from_case(cls, case, rank, nranks, planes=None, device=-1, halo_room=None, **overrides):
+        planes = planes or choose_planes(case, nranks)
+        p, _, _ = capi.case_params(case)
+        st, gids = capi.case_init_range(case, planes[rank], planes[rank + 1])
+        n = len(gids)
+        if n == 0:
+            raise capi.SphError("rank %d owns no particle" % rank)
+        p.npts_global = p.npts
+        p.npts = n
+        p.rank, p.nranks = rank, nranks
+        room = halo_room if halo_room is not None else max(1 << 16, n // 8)
+        p.capacity = n + 2 * room
+        big = 1e300
+        p.slab_lo = max(planes[rank], -big)
+        p.slab_hi = min(planes[rank + 1], big)
+        p.device = device
+        for k, v in overrides.items():
+            setattr(p, k, v)
+        sim = cls(p)
+        sim.global_ids = gids
+        sim.npts_global = int(p.npts_global)
+        sim.upload(capi.STATE_N, st)
+        sim.upload(capi.STATE_NP1, st)
+        sim.upload_global_ids(gids)
+        return sim
+
+
+def gather_state(sim, state, dist, group=None):
+    """All ranks' downloaded `state` dicts merged into global original order (on every rank)."""
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, (sim.global_ids, state), group=group)
+    n = sim.npts_global
+    out = {}
+    for k, a in state.items():
+        shape = (a.shape[0], n) if a.ndim == 2 else (n,)
+        out[k] = np.zeros(shape, a.dtype)
+    for g, st in parts:
+        for k, a in st.items():
+            out[k][..., g] = a
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-GPU benchmark (weak scaling: the fluid block and the box grow along x with the ranks)
+
+
+def bench_main(args, world, rank, local_rank, fluid):
+    import torch
+    import torch.distributed as dist
+    import bench as B
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # control plane (id broadcast, barriers, timing) on gloo; particle data moves over RCCL
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nx, ny, nz = fluid
+    case = B.dam_break_3d(nx * world, ny, nz)
+    t_setup = time.perf_counter()
+    sim = SlabSim.from_case(case, rank, world, device=local_rank)
+    ident = [capi.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ident, src=0)
+    sim.use_rccl(ident[0])
+    sim.forces(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    setup_s = time.perf_counter() - t_setup
+
+    for _ in range(args.warmup):
+        sim.step(1)
+    sim.profile_enable(True)
+    sim.profile_read()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    sc = sim.step(args.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = sim.profile_read()
+    t = torch.tensor([elapsed, prof["pair_ms"] / max(prof["pair_launches"], 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    counts = torch.tensor([sim.npts], dtype=torch.int64)
+    allc = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(allc, counts)
+    elapsed, pair_ms = float(t[0]), float(t[1])
+    n = sim.npts_global
+    if rank == 0:
+        value = n * args.steps / elapsed
+        per = [int(c[0]) for c in allc]
+        b_alg = (B.B_ALG_PAIR + B.B_ALG_UPDATE) * max(per)
+        ach = b_alg / (pair_ms * 1e-3) / 1e9
+        out = {
+            "metric": "particle-steps/sec (3-D WCXSPH dam break)",
+            "value": value, "unit": "particle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "C3 x %d along x: WCXSPH3D dam break, Pstep 0.1, fluid %dx%dx%d + walls, "
+                            "box %.1fx%.1fx%.1f, %d x-slabs, halo exchange over RCCL send/recv"
+                            % (world, nx * world, ny, nz, case.box[0], case.box[1], case.box[2], world),
+                "particles": n, "particles_per_rank": per, "sweeps_per_step": 8,
+                "list_rebuilds": prof["rebuilds"], "step_redos": sc["step_redos"], "setup_s": setup_s,
+            },
+            "roofline": {
+                "kernel": "k_pair<3,xsph,fused>, the three launches of one sweep (two boundary layers + interior), slowest rank",
+                "bound": "hbm", "achieved": ach, "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / B.HBM_PEAK_GBS, "traffic": None, "kernel_ms": pair_ms,
+            },
+        }
+        print(json.dumps(out), flush=True)
+    sim.close()
+    dist.barrier()
+    dist.destroy_process_group()

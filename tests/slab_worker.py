@@ -1,0 +1,88 @@
+"""One rank of a slab-decomposed run (started by test_gpu_slabs.py, one process per rank, all
+on the same GPU, bytes moved through gloo).  Rank 0 writes the merged results to --out."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--spec", required=True, help="JSON: arguments of capi.make_case or {program}")
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--skin", type=float, default=0.0)
+    ap.add_argument("--jitter", type=float, default=0.0)
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from sph_amd import capi, domain
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = json.loads(args.spec)
+    if "npart" in spec:
+        case = capi.make_case(spec["program"], spec["npart"], spec["pstep"], spec["box"], spec["start"])
+    else:
+        case = capi.default_case(spec["program"])
+    over = {"skin_frac": args.skin} if args.skin > 0 else {}
+    sim = domain.SlabSim.from_case(case, rank, world, device=0, **over)
+    tr = domain.HostTransport(rank, world)
+    sim.set_transport(tr.struct)
+    if args.jitter > 0:
+        # the same perturbation of the whole set on every rank, then each takes its own rows
+        p, st = capi.case_init(case)
+        rng = np.random.Generator(np.random.MT19937(4321))
+        dx = rng.uniform(-args.jitter, args.jitter, size=st["x"].shape) * case.pstep
+        dx[:, : int(p.bound_parts)] = 0.0
+        mine = {"x": np.ascontiguousarray((st["x"] + dx)[:, sim.global_ids])}
+        sim.upload(capi.STATE_N, mine, names=("x",))
+        sim.upload(capi.STATE_NP1, mine, names=("x",))
+
+    res = {}
+    sim.forces(capi.STATE_N)
+    f0 = sim.download(capi.STATE_N, names=("f", "V", "Rrho"))
+    offs, cols = sim.neighbours(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    sc = sim.step(args.steps)
+    st = sim.download(capi.STATE_N)
+    g0 = domain.gather_state(sim, f0, dist)
+    g1 = domain.gather_state(sim, st, dist)
+    rows = [None] * world
+    dist.all_gather_object(rows, (sim.global_ids, offs, cols))
+    if rank == 0:
+        for k, a in g0.items():
+            res["forces_" + k] = a
+        for k, a in g1.items():
+            res["step_" + k] = a
+        n = sim.npts_global
+        counts = np.zeros(n, np.int64)
+        for g, o, c in rows:
+            counts[g] = np.diff(o.astype(np.int64))
+        goffs = np.concatenate(([0], np.cumsum(counts)))
+        gcols = np.zeros(int(goffs[-1]), np.uint32)
+        for g, o, c in rows:
+            o = o.astype(np.int64)
+            for i, gi in enumerate(g):
+                gcols[goffs[gi]:goffs[gi + 1]] = c[o[i]:o[i + 1]]
+        res["nbr_offs"], res["nbr_cols"] = goffs, gcols
+        res["scalars"] = np.array([sc["dt"], sc["t"], sc["maxmu"], sc["maxf"], sc["errsum"], sc["logbase"],
+                                   float(sc["hit_pairs"]), float(sc["step_redos"]), float(sc["list_rebuilds"])])
+        res["per_rank"] = np.array([len(r[0]) for r in rows])
+        np.savez(args.out, **res)
+    if tr.error is not None:
+        raise tr.error
+    sim.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d done" % rank, flush=True)
+
+
+if __name__ == "__main__":
+    main()

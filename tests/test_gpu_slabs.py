@@ -1,0 +1,115 @@
+"""GPU parity of the slab-decomposed path: 2 and 3 ranks (one process each, sharing the one
+GPU, halo bytes moved through gloo by the host-buffer transport) against the CPU oracle on the
+whole domain.  Same bars as test_gpu_parity.py: neighbour sets bit-exact (global indices),
+double fields within 1e-10 relative, float fields within one float ulp.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = 1e-10
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run_slabs(spec, nranks, tmp_path, steps=2, skin=0.0, jitter=0.0):
+    out = str(tmp_path / "slabs.npz")
+    port = free_port()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_RANK=str(r),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        cmd = [sys.executable, "-u", os.path.join(HERE, "slab_worker.py"), "--spec", json.dumps(spec),
+               "--steps", str(steps), "--skin", str(skin), "--jitter", str(jitter), "--out", out]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs, bad = [], False
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+            bad = True
+        logs.append(o.decode(errors="replace"))
+        bad = bad or p.returncode != 0
+    assert not bad, "slab run failed:\n" + "\n-----\n".join(logs)
+    return np.load(out)
+
+
+def oracle_run(spec, steps, jitter=0.0):
+    oc, _ = util.both_cases(spec)
+    orc = O.Oracle(oc)
+    if jitter > 0:
+        st = orc.get_state(O.STATE_N)
+        rng = np.random.Generator(np.random.MT19937(4321))
+        dx = rng.uniform(-jitter, jitter, size=st["x"].T.shape) * oc.pstep  # drawn component-major, as the worker does
+        dx[:, : orc.bound_parts] = 0.0
+        x = st["x"] + dx.T
+        orc.set_state(O.STATE_N, x=x)
+        orc.set_state(O.STATE_NP1, x=x)
+    orc.forces(O.STATE_N)
+    f0 = orc.get_state(O.STATE_N)
+    nb = orc.neighbours(O.STATE_N)
+    orc.zero_boundary_f(O.STATE_N)
+    orc.step(steps)
+    return orc, f0, nb
+
+
+def check(res, orc, f0, nb, what):
+    for k in ("f", "V"):
+        err = util.rel_err(res["forces_" + k].T, f0[k])
+        assert err <= TOL, "%s: Forces %s off by %.3e" % (what, k, err)
+    s = max(float(np.max(np.abs(f0["Rrho"]))), 1e-30)
+    assert float(np.max(np.abs(res["forces_Rrho"].astype(np.float64) - f0["Rrho"]))) <= 1e-6 * s, what
+    assert np.array_equal(res["nbr_offs"], nb[0].astype(np.int64)), what + ": neighbour counts"
+    assert np.array_equal(res["nbr_cols"], nb[1]), what + ": neighbour columns"
+    o = orc.get_state(O.STATE_N)
+    for k in ("x", "v", "V", "f"):
+        err = util.rel_err(res["step_" + k].T, o[k])
+        assert err <= TOL, "%s: after the steps, %s off by %.3e" % (what, k, err)
+    for k in ("rho", "p"):
+        u = util.float_ulp_diff(res["step_" + k], o[k])
+        assert u.max() <= 1, "%s: %s differs by %d float ulp" % (what, k, u.max())
+    osc = orc.scalars()
+    dt, t, maxmu, maxf, errsum, logbase = res["scalars"][:6]
+    for a, b, n in ((dt, osc["dt"], "dt"), (maxmu, osc["maxmu"], "maxmu"), (maxf, osc["maxf"], "maxf")):
+        assert abs(a - b) <= 1e-12 * max(abs(b), 1e-300), "%s: %s %r vs %r" % (what, n, a, b)
+    assert abs(errsum - osc["errsum"]) <= 1e-9 * max(abs(osc["errsum"]), 1e-300), what
+    assert abs(logbase - osc["logbase"]) <= 1e-9 * max(abs(osc["logbase"]), 1.0), what
+
+
+@pytest.mark.parametrize("name,nranks", [("wcxsph3d_block", 2), ("wcxsph3d_block", 3), ("wcxsph_fine", 2),
+                                         ("wcsph_fine", 3)])
+def test_slabs_match_the_whole_domain(name, nranks, tmp_path):
+    spec = util.small_cases()[name]
+    res = run_slabs(spec, nranks, tmp_path, steps=3)
+    assert len(res["per_rank"]) == nranks and res["per_rank"].min() > 0
+    orc, f0, nb = oracle_run(spec, 3)
+    check(res, orc, f0, nb, "%s on %d slabs" % (name, nranks))
+
+
+def test_slabs_on_jittered_positions_with_a_tight_skin(tmp_path):
+    # a tight skin forces list rebuilds (fresh halo selections) and step redos on every rank
+    spec = util.small_cases()["wcxsph3d_block"]
+    res = run_slabs(spec, 2, tmp_path, steps=4, skin=0.002, jitter=0.01)
+    orc, f0, nb = oracle_run(spec, 4, jitter=0.01)
+    check(res, orc, f0, nb, "jittered block on 2 slabs")
+    assert res["scalars"][8] >= 4  # rebuilds happened
