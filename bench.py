@@ -40,6 +40,21 @@ def dam_break_3d(nx, ny, nz):
     return capi.make_case(capi.PROGRAM_WCXSPH3D, (nx, ny, nz), pstep, box, start)
 
 
+def measured_traffic(fluid, n):
+    """HBM bytes per launch of the pair kernel from the committed counter run of this same
+    workload (rocprofv3 cannot run inside this process): FETCH_SIZE with its gfx950 correction
+    + WRITE_SIZE.  None when no counter run matches the workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pair_traffic.json")) as fh:
+            t = json.load(fh)
+    except OSError:
+        return None
+    if list(t["workload"]["fluid"]) != list(fluid) or t["particles"] != n:
+        return None
+    reads = t["fetch_size_kib"] * 1024.0 + 0.5 * t["streamed_read_bytes_per_particle"] * n
+    return reads + t["write_size_kib"] * 1024.0
+
+
 def cpu_baseline(sample=(64, 48, 32), steps=1):
     """The oracle (a port: the reference itself needs Eigen+nanoflann) on one host core, on
     a reduced block of the same case."""
@@ -82,6 +97,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the pair path has no CPU fallback")
+    # one GPU per rank; ranks wrap round only on a development box with fewer GPUs than ranks
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 
     nx, ny, nz = (int(v) for v in args.fluid.lower().split("x"))
@@ -134,7 +151,9 @@ def main():
         "roofline": {
             "kernel": "k_pair<3,xsph,fused> (Forces + wall reset + Newmark update + EOS, one launch per sweep)",
             "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+            "frac": ach_gbs / HBM_PEAK_GBS, "traffic": measured_traffic((nx, ny, nz), n),
+            "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE of this workload, profiles/pair_traffic.json)",
+            "algorithmic_bytes_per_launch": b_alg,
             "kernel_ms": pair_ms, "launches": prof["pair_launches"],
             "algorithmic_bytes_per_particle_sweep": B_ALG_PAIR + B_ALG_UPDATE,
             "fp64": {"achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -1435,9 +1435,13 @@ int sph_use_rccl(sph_ctx* c, const void* unique_id_128) {
     r->nranks = c->nranks;
     ncclUniqueId id;
     memcpy(&id, unique_id_128, sizeof id);
-    if (r->CommInitRank(&r->comm, c->nranks, id, c->rank) != ncclSuccess) {
+    const ncclResult_t ir = r->CommInitRank(&r->comm, c->nranks, id, c->rank);
+    if (ir != ncclSuccess) {
+        auto es = (const char* (*)(ncclResult_t))dlsym(r->lib, "ncclGetErrorString");
+        auto le = (const char* (*)(ncclComm_t))dlsym(r->lib, "ncclGetLastError");
+        c->err = std::string("ncclCommInitRank failed: ") + (es ? es(ir) : "?") + " / " + (le ? le(nullptr) : "");
         delete r;
-        return fail(c, SPH_ECOMM, "ncclCommInitRank failed");
+        return SPH_ECOMM;
     }
     c->rccl = r;
     c->rccl_free = rccl_release;

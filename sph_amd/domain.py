@@ -166,9 +166,29 @@ def bench_main(args, world, rank, local_rank, fluid):
     case = B.dam_break_3d(nx * world, ny, nz)
     t_setup = time.perf_counter()
     sim = SlabSim.from_case(case, rank, world, device=local_rank)
-    ident = [capi.rccl_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(ident, src=0)
-    sim.use_rccl(ident[0])
+    transport = os.environ.get("SPH_TRANSPORT", "rccl")
+    if transport == "rccl":
+        ident = [capi.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        why = None
+        try:
+            sim.use_rccl(ident[0])
+        except capi.SphError as e:
+            why = str(e)
+        failed = torch.tensor([1 if why else 0], dtype=torch.int32)
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if int(failed[0]):
+            # no communicator (e.g. ranks sharing a GPU): every rank moves to the staged transport
+            if why and rank == 0:
+                print("RCCL transport unavailable (%s); halo bytes staged through the host" % why, flush=True)
+            transport = "host"
+    if transport == "rccl":
+        pass
+    elif transport == "host":  # ranks sharing a GPU on a development box: staged through gloo
+        host_tr = HostTransport(rank, world)
+        sim.set_transport(host_tr.struct)
+    else:
+        raise SystemExit("SPH_TRANSPORT must be rccl or host")
     sim.forces(capi.STATE_N)
     sim.zero_boundary_forces(capi.STATE_N)
     setup_s = time.perf_counter() - t_setup
@@ -206,8 +226,9 @@ def bench_main(args, world, rank, local_rank, fluid):
             "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": "C3 x %d along x: WCXSPH3D dam break, Pstep 0.1, fluid %dx%dx%d + walls, "
-                            "box %.1fx%.1fx%.1f, %d x-slabs, halo exchange over RCCL send/recv"
-                            % (world, nx * world, ny, nz, case.box[0], case.box[1], case.box[2], world),
+                            "box %.1fx%.1fx%.1f, %d x-slabs, halo exchange over %s"
+                            % (world, nx * world, ny, nz, case.box[0], case.box[1], case.box[2], world,
+                               "RCCL send/recv" if transport == "rccl" else "host staging + gloo"),
                 "particles": n, "particles_per_rank": per, "sweeps_per_step": 8,
                 "list_rebuilds": prof["rebuilds"], "step_redos": sc["step_redos"], "setup_s": setup_s,
             },
