@@ -63,13 +63,20 @@ typedef struct sph_params {
     int32_t  device;           /* HIP device ordinal; -1 = current device */
     /* Slab decomposition along x, one context per GPU (no counterpart in the reference, which
      * is one process on one core).  nranks <= 1: a single domain, the fields below are unused.
-     * Otherwise npts is the number of particles this rank owns, npts_global the total (the
-     * convergence diagnostic divides by it, WCXSPH3D.cpp:288), capacity the room for owned
-     * plus halo particles, and [slab_lo, slab_hi) the x-interval this rank owns. */
+     * Otherwise npts is the number of particles this rank owns at first, npts_global the total
+     * (the convergence diagnostic divides by it, WCXSPH3D.cpp:288), and [slab_lo, slab_hi) the
+     * x-interval this rank owns.  capacity > npts is the room per array: of the excess, half
+     * lets the owned set grow by migration, a quarter each holds the left and right halo (and
+     * bounds how many particles may cross one plane between two list rebuilds).  migrate != 0:
+     * at the list rebuild that opens a step, particles outside [slab_lo, slab_hi) are handed to
+     * the neighbour on that side; the local order of upload/download is then renumbered (see
+     * sph_local_count). */
     int32_t  rank, nranks;
     uint64_t npts_global;
     uint64_t capacity;
     double   slab_lo, slab_hi;
+    int32_t  migrate;
+    int32_t  reserved_;
 } sph_params;
 
 /* Caller-owned host arrays in ORIGINAL particle order, one array per component
@@ -173,6 +180,11 @@ int sph_set_transport(sph_ctx* ctx, const sph_transport* t);
 /* Global original indices of this rank's particles, in upload order (wall particles are the
  * ones below bound_parts of the GLOBAL numbering).  Required when nranks > 1. */
 int sph_upload_global_ids(sph_ctx* ctx, const uint32_t* gids);
+/* Particles this rank owns now, and how many it has received / handed over so far.  After a
+ * migration the arrays of sph_upload/sph_download have this many entries, in an order that
+ * sph_download_global_ids reports (entry k belongs to the particle with that global index). */
+int sph_local_count(sph_ctx* ctx, uint64_t* npts, uint64_t* migrated_in, uint64_t* migrated_out);
+int sph_download_global_ids(sph_ctx* ctx, uint32_t* gids);
 /* A transport over RCCL (ncclSend/ncclRecv/ncclAllReduce on the context's device).
  * `unique_id` is the 128-byte ncclUniqueId, identical on all ranks (rank 0 obtains it with
  * sph_rccl_unique_id and the launcher broadcasts it). */

@@ -25,7 +25,7 @@ SYMBOLS = (
     "sph_density_reinit", "sph_neighbours", "sph_profile_enable", "sph_profile_read",
     "sph_case_default", "sph_case_params", "sph_case_init",
     "sph_set_transport", "sph_upload_global_ids", "sph_rccl_unique_id", "sph_use_rccl",
-    "sph_case_init_range", "sph_case_histogram_x",
+    "sph_case_init_range", "sph_case_histogram_x", "sph_local_count", "sph_download_global_ids",
 )
 
 
@@ -39,7 +39,8 @@ class Params(C.Structure):
                 ("mass", C.c_double), ("dt0", C.c_double), ("skin_frac", C.c_double),
                 ("max_neighbours", C.c_int32), ("device", C.c_int32),
                 ("rank", C.c_int32), ("nranks", C.c_int32), ("npts_global", C.c_uint64),
-                ("capacity", C.c_uint64), ("slab_lo", C.c_double), ("slab_hi", C.c_double)]
+                ("capacity", C.c_uint64), ("slab_lo", C.c_double), ("slab_hi", C.c_double),
+                ("migrate", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class Fields(C.Structure):
@@ -114,6 +115,8 @@ def lib():
     L.sph_case_init.argtypes = [C.POINTER(Case), C.POINTER(Fields)]
     L.sph_set_transport.argtypes = [vp, C.POINTER(Transport)]
     L.sph_upload_global_ids.argtypes = [vp, vp]
+    L.sph_local_count.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.sph_download_global_ids.argtypes = [vp, vp]
     L.sph_rccl_unique_id.argtypes = [vp]
     L.sph_use_rccl.argtypes = [vp, vp]
     L.sph_case_init_range.argtypes = [C.POINTER(Case), C.c_double, C.c_double, C.POINTER(Fields), vp,
@@ -300,6 +303,16 @@ class Sim:
         g = np.ascontiguousarray(gids, np.uint32)
         assert g.shape == (self.npts,)
         self._chk(lib().sph_upload_global_ids(self._h, g.ctypes.data), "sph_upload_global_ids")
+
+    def local_count(self):
+        n, mi, mo = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(lib().sph_local_count(self._h, C.byref(n), C.byref(mi), C.byref(mo)), "sph_local_count")
+        return int(n.value), int(mi.value), int(mo.value)
+
+    def download_global_ids(self):
+        g = np.zeros(self.npts, np.uint32)
+        self._chk(lib().sph_download_global_ids(self._h, g.ctypes.data), "sph_download_global_ids")
+        return g
 
     def forces(self, which):
         self._chk(lib().sph_forces(self._h, which), "sph_forces")

@@ -95,7 +95,13 @@ struct sph_ctx {
     bool dist = false;
     int rank = 0, nranks = 1;
     bool has_side[2] = {false, false}; /* a neighbour on the left / right */
-    uint32_t halo_cap = 0;             /* per side */
+    uint32_t halo_cap = 0;             /* per side: halo particles, and particles migrating per rebuild */
+    uint32_t own_cap = 0;              /* most particles this rank may come to own */
+    bool migrate = false;
+    uint32_t* drop = nullptr;          /* 1: handed to a neighbour in the rebuild under way */
+    Mig *migsend = nullptr, *migrecv = nullptr; /* [2][halo_cap] */
+    size_t stage_half = 0;             /* bytes per side in the pinned staging buffers */
+    uint64_t migrated_in = 0, migrated_out = 0;
     uint32_t nsend[2] = {0, 0}, nrecv[2] = {0, 0};
     uint32_t* send_idx = nullptr;  /* [2][halo_cap] cell-order positions of the particles sent */
     uint32_t* halo_pos = nullptr;  /* [2*halo_cap] where the k-th received particle lives */
@@ -213,10 +219,10 @@ int radix_sort(sph_ctx* c, uint32_t*& keys, uint32_t*& keys_alt, uint32_t*& perm
     return SPH_OK;
 }
 
-void launch_hash(sph_ctx* c, const Rec* r, uint32_t m, uint32_t* keys) {
+void launch_hash(sph_ctx* c, const Rec* r, uint32_t m, const uint32_t* drop, uint32_t* keys) {
     if (m == 0) return;
-    if (c->dim == 3) hipLaunchKernelGGL(k_hash<3>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, c->grid, keys);
-    else hipLaunchKernelGGL(k_hash<2>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, c->grid, keys);
+    if (c->dim == 3) hipLaunchKernelGGL(k_hash<3>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, c->grid, drop, keys);
+    else hipLaunchKernelGGL(k_hash<2>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, c->grid, drop, keys);
 }
 
 int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
@@ -241,7 +247,7 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
         const uint32_t newcap = (need + need / 8 + 7u) & ~3u;
         HIPCHK(hipFree(c->nbr));
         c->nbr = nullptr;
-        CHK(dalloc(c, &c->nbr, (size_t)newcap * c->n));
+        CHK(dalloc(c, &c->nbr, (size_t)newcap * c->own_cap));
         c->cap_k = newcap;
     }
     return fail(c, SPH_ESTATE, "candidate lists kept overflowing");
@@ -258,7 +264,7 @@ int exchange_bytes(sph_ctx* c, const void* sL, size_t nsL, void* rL, size_t nrL,
             return fail(c, SPH_ECOMM, "transport sendrecv failed");
         return SPH_OK;
     }
-    const size_t half = (size_t)c->halo_cap * sizeof(Rec);
+    const size_t half = c->stage_half;
     if (nsL) HIPCHK(hipMemcpyAsync(c->h_send, sL, nsL, hipMemcpyDeviceToHost, c->comm));
     if (nsR) HIPCHK(hipMemcpyAsync(c->h_send + half, sR, nsR, hipMemcpyDeviceToHost, c->comm));
     HIPCHK(hipStreamSynchronize(c->comm));
@@ -281,6 +287,29 @@ int allreduce_host(sph_ctx* c, double* vals, int n, int op) {
         return fail(c, SPH_ECOMM, "transport allreduce failed");
     HIPCHK(hipMemcpyAsync(vals, c->red_dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->comm));
     HIPCHK(hipStreamSynchronize(c->comm));
+    return SPH_OK;
+}
+
+/* Exchange the counts a rank is about to send to each side; returns what it will receive. */
+int exchange_counts(sph_ctx* c, const uint32_t send[2], uint32_t recv[2]) {
+    uint64_t s[2] = {send[0], send[1]}, r[2] = {0, 0};
+    uint64_t* ds = (uint64_t*)c->red_dev; /* scratch: [0..1] send, [2..3] recv */
+    HIPCHK(hipMemcpyAsync(ds, s, sizeof s, hipMemcpyHostToDevice, c->comm));
+    HIPCHK(hipMemsetAsync(ds + 2, 0, 16, c->comm));
+    CHK(exchange_bytes(c, ds, c->has_side[0] ? 8 : 0, ds + 2, c->has_side[0] ? 8 : 0, ds + 1, c->has_side[1] ? 8 : 0,
+                       ds + 3, c->has_side[1] ? 8 : 0));
+    HIPCHK(hipMemcpyAsync(r, ds + 2, sizeof r, hipMemcpyDeviceToHost, c->comm));
+    HIPCHK(hipStreamSynchronize(c->comm));
+    recv[0] = (uint32_t)std::min<uint64_t>(r[0], UINT32_MAX);
+    recv[1] = (uint32_t)std::min<uint64_t>(r[1], UINT32_MAX);
+    return SPH_OK;
+}
+
+/* Every rank reports a local failure; all of them stop if any did (nobody is left waiting). */
+int agree_ok(sph_ctx* c, bool local_ok, int code, const char* msg) {
+    double bad[1] = {local_ok ? 0.0 : 1.0};
+    CHK(allreduce_host(c, bad, 1, 0));
+    if (bad[0] != 0.0) return fail(c, code, msg);
     return SPH_OK;
 }
 
@@ -325,20 +354,13 @@ int exchange_halo_at_rebuild(sph_ctx* c, int src, const double thr[2]) {
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
-    /* counts first: through the same transport, as 8-byte messages in the staging buffers */
     {
-        uint64_t s[2] = {c->nsend[0], c->nsend[1]}, r[2] = {0, 0};
-        uint64_t* ds = (uint64_t*)c->red_dev; /* scratch: [0..1] send, [2..3] recv */
-        HIPCHK(hipMemcpyAsync(ds, s, sizeof s, hipMemcpyHostToDevice, c->comm));
-        HIPCHK(hipMemsetAsync(ds + 2, 0, 16, c->comm));
-        CHK(exchange_bytes(c, ds, c->has_side[0] ? 8 : 0, ds + 2, c->has_side[0] ? 8 : 0, ds + 1, c->has_side[1] ? 8 : 0,
-                           ds + 3, c->has_side[1] ? 8 : 0));
-        HIPCHK(hipMemcpyAsync(r, ds + 2, sizeof r, hipMemcpyDeviceToHost, c->comm));
-        HIPCHK(hipStreamSynchronize(c->comm));
-        if (r[0] > c->halo_cap || r[1] > c->halo_cap)
-            return fail(c, SPH_ENOMEM, "incoming halo larger than the capacity given at sph_create");
-        c->nrecv[0] = (uint32_t)r[0];
-        c->nrecv[1] = (uint32_t)r[1];
+        uint32_t arrive[2] = {0, 0};
+        CHK(exchange_counts(c, c->nsend, arrive));
+        CHK(agree_ok(c, arrive[0] <= c->halo_cap && arrive[1] <= c->halo_cap, SPH_ENOMEM,
+                     "incoming halo larger than the capacity given at sph_create"));
+        c->nrecv[0] = arrive[0];
+        c->nrecv[1] = arrive[1];
     }
     const size_t hc = c->halo_cap;
     CHK(exchange_bytes(c, c->sendbuf, (size_t)c->nsend[0] * sizeof(Rec), c->recvbuf, (size_t)c->nrecv[0] * sizeof(Rec),
@@ -351,7 +373,7 @@ int exchange_halo_at_rebuild(sph_ctx* c, int src, const double thr[2]) {
 
     /* place behind the owned particles: left block, then right block */
     const uint32_t m = c->nrecv[0] + c->nrecv[1];
-    if (n + m > c->cap) return fail(c, SPH_ENOMEM, "owned + halo particles exceed the capacity");
+    CHK(agree_ok(c, (uint64_t)n + m <= c->cap, SPH_ENOMEM, "owned + halo particles exceed the capacity"));
     Rec* r = c->rec[src];
     if (c->nrecv[0]) {
         HIPCHK(hipMemcpyAsync(r + n, c->recvbuf, (size_t)c->nrecv[0] * sizeof(Rec), hipMemcpyDeviceToDevice, c->stream));
@@ -367,7 +389,7 @@ int exchange_halo_at_rebuild(sph_ctx* c, int src, const double thr[2]) {
     if (m == 0) return SPH_OK;
     hipLaunchKernelGGL(k_fill<uint32_t>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, c->id + n, SPH_HALO_ID, m);
     /* sort the halo region by cell */
-    launch_hash(c, r + n, m, c->keys + n);
+    launch_hash(c, r + n, m, nullptr, c->keys + n);
     uint32_t *k = c->keys + n, *ka = c->keys_alt + n, *p = c->perm + n, *pa = c->perm_alt + n;
     CHK(radix_sort(c, k, ka, p, pa, m, c->grid.ncells));
     if (k != c->keys + n) HIPCHK(hipMemcpyAsync(c->keys + n, k, (size_t)m * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -383,11 +405,82 @@ int exchange_halo_at_rebuild(sph_ctx* c, int src, const double thr[2]) {
     return SPH_OK;
 }
 
+MigArgs mig_args(sph_ctx* c, int src) {
+    MigArgs a;
+    memset(&a, 0, sizeof a);
+    for (int q = 0; q < 12; ++q) a.nd[q] = c->nd[q];
+    for (int q = 0; q < 6; ++q) a.pd[q] = c->pd[q];
+    for (int q = 0; q < 4; ++q) a.nfl[q] = c->nfl[q];
+    a.pRrho = c->pRrho;
+    a.pp = c->pp;
+    a.rec = c->rec[src];
+    a.gid = c->gid;
+    return a;
+}
+
+/* Hands the particles that left [slab_lo, slab_hi) to the neighbour on that side and appends
+ * the ones the neighbours hand over behind the owned particles.  The leavers stay in place,
+ * marked in c->drop; the sort that follows moves them behind every cell.  On return *m_sort
+ * is the number of entries to sort and *n_new the number of particles owned from now on. */
+int migrate_particles(sph_ctx* c, int src, uint32_t* m_sort, uint32_t* n_new) {
+    const uint32_t n = c->n;
+    const size_t hc = c->halo_cap;
+    HIPCHK(hipMemsetAsync(c->drop, 0, sizeof(uint32_t) * c->cap, c->stream));
+    uint32_t counts[2] = {0, 0};
+    bool fits = true;
+    for (int side = 0; side < 2; ++side) {
+        if (!c->has_side[side]) continue;
+        const double plane = side == 0 ? c->prm.slab_lo : c->prm.slab_hi;
+        hipLaunchKernelGGL(k_flag_leavers, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->rec[src], n, side, plane, c->flags,
+                           c->drop);
+        CHK(exclusive_scan(c, c->flags, c->fpos, n));
+        hipLaunchKernelGGL(k_compact, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->flags, c->fpos, n, c->halo_cap,
+                           c->send_idx + side * hc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&c->need_host[2], c->fpos + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&c->need_host[3], c->flags + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        counts[side] = c->need_host[2] + c->need_host[3];
+        if (counts[side] > c->halo_cap) fits = false;
+    }
+    if (counts[0] + counts[1] >= n) fits = false; /* a rank must keep at least one particle */
+    CHK(agree_ok(c, fits, SPH_ENOMEM, "more particles leave a slab at once than the capacity given at sph_create allows"));
+    MigArgs a = mig_args(c, src);
+    for (int side = 0; side < 2; ++side)
+        if (counts[side])
+            hipLaunchKernelGGL(k_pack_mig, dim3(nblk(counts[side])), dim3(SPH_BLOCK), 0, c->stream, a, c->send_idx + side * hc,
+                               counts[side], c->migsend + side * hc);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint32_t arrive[2] = {0, 0};
+    CHK(exchange_counts(c, counts, arrive));
+    const uint64_t na = (uint64_t)arrive[0] + arrive[1];
+    const bool room = arrive[0] <= c->halo_cap && arrive[1] <= c->halo_cap &&
+                      (uint64_t)n - counts[0] - counts[1] + na <= c->own_cap && (uint64_t)n + na <= c->cap;
+    CHK(agree_ok(c, room, SPH_ENOMEM, "a slab received more particles than the capacity given at sph_create allows"));
+    CHK(exchange_bytes(c, c->migsend, (size_t)counts[0] * sizeof(Mig), c->migrecv, (size_t)arrive[0] * sizeof(Mig),
+                       c->migsend + hc, (size_t)counts[1] * sizeof(Mig), c->migrecv + hc, (size_t)arrive[1] * sizeof(Mig)));
+    HIPCHK(hipStreamSynchronize(c->comm));
+    if (arrive[0])
+        hipLaunchKernelGGL(k_unpack_mig, dim3(nblk(arrive[0])), dim3(SPH_BLOCK), 0, c->stream, a, c->migrecv, arrive[0], n);
+    if (arrive[1])
+        hipLaunchKernelGGL(k_unpack_mig, dim3(nblk(arrive[1])), dim3(SPH_BLOCK), 0, c->stream, a, c->migrecv + hc, arrive[1],
+                           n + arrive[0]);
+    HIPCHK(hipGetLastError());
+    if (na) /* positions in the caller's arrays mean nothing for newcomers; the order is renumbered below */
+        hipLaunchKernelGGL(k_fill<uint32_t>, dim3(nblk((uint32_t)na)), dim3(SPH_BLOCK), 0, c->stream, c->id + n, 0u, (uint32_t)na);
+    *m_sort = n + (uint32_t)na;
+    *n_new = n - counts[0] - counts[1] + (uint32_t)na;
+    c->migrated_out += counts[0] + counts[1];
+    c->migrated_in += na;
+    return SPH_OK;
+}
+
 /* Re-bin on the positions held in record buffer `src`, bring every live array into the new
  * cell order, (slab runs) fetch the neighbours' boundary particles, rebuild cell table and
  * candidate lists, reset the travel bound.  Collective in a slab run. */
-int rebuild(sph_ctx* c, int src, bool for_step = false) {
-    const uint32_t n = c->n;
+int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false) {
+    uint32_t n = c->n;
     const int dim = c->dim;
     if (c->dist && !c->have_tr) return fail(c, SPH_ESTATE, "no transport installed (sph_set_transport / sph_use_rccl)");
     EventPair* ev = nullptr;
@@ -402,13 +495,24 @@ int rebuild(sph_ctx* c, int src, bool for_step = false) {
         HIPCHK(hipEventRecord(ev->a, c->stream));
     }
     c->n_halo = 0; /* the neighbours' particles are fetched afresh below */
+    uint32_t m_sort = n;
+    const uint32_t* drop = nullptr;
+    const uint32_t n_before = n;
+    bool renumber = false;
+    if (c->dist && c->migrate && may_migrate && src == c->b0) {
+        uint32_t n_new = n;
+        CHK(migrate_particles(c, src, &m_sort, &n_new));
+        renumber = m_sort != n || n_new != n;
+        drop = c->drop;
+        n = n_new; /* kernels below that walk the owned particles before the sort use m_sort and drop */
+    }
 
     /* inside a step, wall-wall pairs can be dropped while the walls are at rest */
     double walls_move = 1.0;
     if (for_step && c->dp.bound_parts > 0) {
         WallRestArgs w;
         memset(&w, 0, sizeof w);
-        w.n = n;
+        w.n = m_sort;
         w.wall_below = c->dp.bound_parts;
         w.dim = dim;
         w.xsph = c->xsph;
@@ -420,12 +524,12 @@ int rebuild(sph_ctx* c, int src, bool for_step = false) {
         }
         w.id = wall_ids(c);
         HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL(k_walls_at_rest, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, w, c->need);
+        hipLaunchKernelGGL(k_walls_at_rest, dim3(nblk(m_sort)), dim3(SPH_BLOCK), 0, c->stream, w, c->need);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     }
     /* bounding box */
-    hipLaunchKernelGGL(k_bbox, dim3(BBOX_BLOCKS), dim3(SPH_BLOCK), 0, c->stream, c->rec[src], n, dim, c->bbox_part);
+    hipLaunchKernelGGL(k_bbox, dim3(BBOX_BLOCKS), dim3(SPH_BLOCK), 0, c->stream, c->rec[src], m_sort, dim, drop, c->bbox_part);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->bbox_host, c->bbox_part, sizeof(double) * 6 * BBOX_BLOCKS, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -514,8 +618,12 @@ int rebuild(sph_ctx* c, int src, bool for_step = false) {
     c->grid = g;
 
     /* sort the owned particles by cell */
-    launch_hash(c, c->rec[src], n, c->keys);
-    CHK(radix_sort(c, c->keys, c->keys_alt, c->perm, c->perm_alt, n, g.ncells));
+    launch_hash(c, c->rec[src], m_sort, drop, c->keys);
+    CHK(radix_sort(c, c->keys, c->keys_alt, c->perm, c->perm_alt, m_sort, g.ncells + (drop ? 1u : 0u)));
+    /* the leavers sorted behind every cell; from here on this rank owns n particles */
+    c->n = n;
+    c->dp.n = n;
+    (void)n_before;
 
     /* physical reorder of every live array */
     ReorderArgs a;
@@ -580,6 +688,8 @@ int rebuild(sph_ctx* c, int src, bool for_step = false) {
     std::swap(c->rec[c->b0], c->rec_alt);
     std::swap(c->id, c->id_alt);
     if (c->dist) std::swap(c->gid, c->gid_alt);
+    if (renumber) /* the set changed: the order of download/upload is this rebuild's cell order from now on */
+        hipLaunchKernelGGL(k_iota, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->id, n);
     if (carried) {
         int freeb = 0;
         while (freeb == src || freeb == c->b0) ++freeb;
@@ -765,7 +875,7 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
         /* mode 0: keep the lists if the travel budget allows; 1: fresh lists at the step's
          * start; 2: fresh lists before every sweep (exact for any motion) */
         if (mode >= 1 || !c->list_valid || !c->lists_for_step || !(c->disp_host <= 0.5 * c->disp_limit))
-            CHK(rebuild(c, c->b0, true));
+            CHK(rebuild(c, c->b0, true, true));
         hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, c->stream, c->S);
         cur = c->b0;
         for (int k = 0; k < nsweeps; ++k) {
@@ -922,8 +1032,11 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     c->xsph = p->variant == SPH_VARIANT_WCXSPH;
     c->n = (uint32_t)p->npts;
     c->cap = c->dist ? (uint32_t)p->capacity : c->n;
-    c->halo_cap = (c->cap - c->n) / 2;
-    c->npairblocks = pairblocks(c->n) + 24; /* up to three launches per sweep, each padded to 8 */
+    /* of the room beyond the first owned set: half for growth by migration, a quarter for each side's halo */
+    c->halo_cap = (c->cap - c->n) / 4;
+    c->own_cap = c->cap - 2 * c->halo_cap;
+    c->migrate = c->dist && p->migrate != 0;
+    c->npairblocks = pairblocks(c->own_cap) + 24; /* up to three launches per sweep, each padded to 8 */
     if (p->skin_frac > 0) c->skin_frac = p->skin_frac;
     c->brick_log2 = c->dim == 3 ? 2u : 3u;
     if (const char* e = getenv("SPH_BRICK_LOG2")) c->brick_log2 = (uint32_t)std::min(5, std::max(0, atoi(e)));
@@ -1000,7 +1113,7 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     CHK(dalloc(c, &c->cend, c->cell_cap));
     c->cap_k = p->max_neighbours > 0 ? (uint32_t)p->max_neighbours : (c->dim == 3 ? 96u : 40u);
     c->cap_k = (c->cap_k + 3u) & ~3u;
-    CHK(dalloc(c, &c->nbr, (size_t)c->cap_k * c->n));
+    CHK(dalloc(c, &c->nbr, (size_t)c->cap_k * c->own_cap));
     CHK(dalloc(c, &c->cnt, n));
     CHK(dalloc(c, &c->need, 8));
     CHK(dalloc(c, &c->S, 1));
@@ -1026,8 +1139,12 @@ int sph_create(const sph_params* p, sph_ctx** out) {
         CHK(dalloc(c, &c->flags, n));
         CHK(dalloc(c, &c->fpos, n));
         CHK(dalloc(c, &c->red_dev, 64 + 2 * (size_t)c->nranks));
-        HIPCHK(hipHostMalloc((void**)&c->h_send, 2 * hc * sizeof(Rec) + 64));
-        HIPCHK(hipHostMalloc((void**)&c->h_recv, 2 * hc * sizeof(Rec) + 64));
+        CHK(dalloc(c, &c->drop, n));
+        CHK(dalloc(c, &c->migsend, 2 * hc));
+        CHK(dalloc(c, &c->migrecv, 2 * hc));
+        c->stage_half = hc * sizeof(Mig) + 64;
+        HIPCHK(hipHostMalloc((void**)&c->h_send, 2 * c->stage_half));
+        HIPCHK(hipHostMalloc((void**)&c->h_recv, 2 * c->stage_half));
         HIPCHK(hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_recvd, hipEventDisableTiming));
@@ -1064,7 +1181,7 @@ void sph_destroy(sph_ctx* c) {
     void* ptrs[] = {c->pp,   c->pp_alt, c->pRrho, c->pRrho_alt, c->id,       c->id_alt,   c->gid,     c->gid_alt, c->keys,
                     c->keys_alt, c->perm, c->perm_alt, c->hist, c->bsum,     c->cbeg,     c->cend,    c->hbeg,    c->hend,
                     c->nbr,  c->cnt,    c->need,  c->S,         c->part,     c->part2,    c->bbox_part, c->tmp,   c->send_idx,
-                    c->halo_pos, c->sendbuf, c->recvbuf, c->sendgid, c->recvgid, c->flags, c->fpos,   c->red_dev};
+                    c->halo_pos, c->sendbuf, c->recvbuf, c->sendgid, c->recvgid, c->flags, c->fpos,   c->red_dev, c->drop, c->migsend, c->migrecv};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->S_host) (void)hipHostFree(c->S_host);
@@ -1095,6 +1212,21 @@ int sph_upload_global_ids(sph_ctx* c, const uint32_t* gids) {
     HIPCHK(hipSetDevice(c->device));
     c->list_valid = false;
     return put_component<uint32_t>(c, c->gid, 1, gids);
+}
+
+int sph_local_count(sph_ctx* c, uint64_t* npts, uint64_t* migrated_in, uint64_t* migrated_out) {
+    if (!c || !npts) return SPH_EINVAL;
+    *npts = c->n;
+    if (migrated_in) *migrated_in = c->migrated_in;
+    if (migrated_out) *migrated_out = c->migrated_out;
+    return SPH_OK;
+}
+
+int sph_download_global_ids(sph_ctx* c, uint32_t* gids) {
+    if (!c || !gids) return SPH_EINVAL;
+    if (!c->dist) return fail(c, SPH_ESTATE, "global ids are only used when nranks > 1");
+    HIPCHK(hipSetDevice(c->device));
+    return get_component<uint32_t>(c, c->gid, 1, gids);
 }
 
 int sph_upload(sph_ctx* c, int32_t which, const sph_fields* s) {

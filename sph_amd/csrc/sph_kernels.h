@@ -67,10 +67,11 @@ __device__ __forceinline__ double wave_min(double v) {
 /* bounding box of finite positions (per-block partials; the host finishes)                   */
 
 __global__ __launch_bounds__(SPH_BLOCK) void k_bbox(const Rec* __restrict__ rec, uint32_t n, int dim,
+                                                    const uint32_t* __restrict__ drop /* may be null */,
                                                     double* __restrict__ part /* [grid][6] */) {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x; i < n; i += gridDim.x * SPH_BLOCK) {
-        bool ok = true;
+        bool ok = !(drop && drop[i]);
         for (int d = 0; d < dim; ++d) ok = ok && isfinite(rec[i].xv[d][0]);
         if (ok)
             for (int d = 0; d < dim; ++d) {
@@ -100,9 +101,14 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_bbox(const Rec* __restrict__ rec,
 
 template <int DIM>
 __global__ __launch_bounds__(SPH_BLOCK) void k_hash(const Rec* __restrict__ rec, uint32_t n, GridParams g,
+                                                    const uint32_t* __restrict__ drop /* may be null */,
                                                     uint32_t* __restrict__ keys) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= n) return;
+    if (drop && drop[i]) { /* handed to a neighbouring slab: sorts behind every cell */
+        keys[i] = g.ncells;
+        return;
+    }
     const int cx = cell_coord(rec[i].xv[0][0], g.lo[0], g.inv[0], g.n[0]);
     const int cy = cell_coord(rec[i].xv[1][0], g.lo[1], g.inv[1], g.n[1]);
     const int cz = DIM == 3 ? cell_coord(rec[i].xv[2][0], g.lo[2], g.inv[2], g.n[2]) : 0;
@@ -1053,6 +1059,68 @@ __global__ void k_lower_bounds(const uint32_t* __restrict__ keys, uint32_t n, ui
         out[q] = lo;
     }
 }
+/* ---- migration: particles that left this slab's interval move to the neighbour ------------- */
+
+/* everything a particle owns: state n, state n+1, the outputs of the last Forces call */
+struct Mig {
+    double nd[12]; /* x, v, V, f of state n */
+    double pd[6];  /* f, V of state n+1 */
+    Rec rec;       /* x, v, rho, m, p/rho^2 of state n+1 */
+    float nfl[4];  /* rho, Rrho, p, m of state n */
+    float pRrho, pp;
+    uint32_t gid, pad;
+};
+struct MigArgs {
+    double* nd[12];
+    double* pd[6];
+    float* nfl[4];
+    float* pRrho;
+    float* pp;
+    Rec* rec;
+    uint32_t* gid;
+};
+/* side 0: x < plane leaves to the left; side 1: x >= plane leaves to the right */
+__global__ __launch_bounds__(SPH_BLOCK) void k_flag_leavers(const Rec* __restrict__ rec, uint32_t n, int side, double plane,
+                                                            uint32_t* __restrict__ flags, uint32_t* __restrict__ drop) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double x = rec[i].xv[0][0];
+    const uint32_t f = side == 0 ? (x < plane ? 1u : 0u) : (x >= plane ? 1u : 0u);
+    flags[i] = f;
+    if (f) drop[i] = 1u;
+}
+__global__ __launch_bounds__(SPH_BLOCK) void k_pack_mig(MigArgs a, const uint32_t* __restrict__ idx, uint32_t m,
+                                                        Mig* __restrict__ out) {
+    const uint32_t k = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t i = idx[k];
+    Mig g;
+    for (int q = 0; q < 12; ++q) g.nd[q] = a.nd[q] ? a.nd[q][i] : 0.0;
+    for (int q = 0; q < 6; ++q) g.pd[q] = a.pd[q] ? a.pd[q][i] : 0.0;
+    for (int q = 0; q < 4; ++q) g.nfl[q] = a.nfl[q][i];
+    g.rec = a.rec[i];
+    g.pRrho = a.pRrho[i];
+    g.pp = a.pp[i];
+    g.gid = a.gid[i];
+    g.pad = 0;
+    out[k] = g;
+}
+__global__ __launch_bounds__(SPH_BLOCK) void k_unpack_mig(MigArgs a, const Mig* __restrict__ in, uint32_t m, uint32_t base) {
+    const uint32_t k = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t i = base + k;
+    const Mig g = in[k];
+    for (int q = 0; q < 12; ++q)
+        if (a.nd[q]) a.nd[q][i] = g.nd[q];
+    for (int q = 0; q < 6; ++q)
+        if (a.pd[q]) a.pd[q][i] = g.pd[q];
+    for (int q = 0; q < 4; ++q) a.nfl[q][i] = g.nfl[q];
+    a.rec[i] = g.rec;
+    a.pRrho[i] = g.pRrho;
+    a.pp[i] = g.pp;
+    a.gid[i] = g.gid;
+}
+
 /* the step's scalars once every rank's values are folded: the same arithmetic as the last
  * k_sweep_finalize, on global maxima and sums (WCXSPH3D.cpp:280-288, 293-298) */
 __global__ void k_apply_global(DevParams P, DevScalars* S, double maxmu, double maxf, double errsum0, double errsum,

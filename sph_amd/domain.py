@@ -108,7 +108,7 @@ class SlabSim(capi.Sim):
     neighbour sets is collective: all ranks call it, in the same order."""
 
     @classmethod
-    def from_case(cls, case, rank, nranks, planes=None, device=-1, halo_room=None, **overrides):
+    def from_case(cls, case, rank, nranks, planes=None, device=-1, halo_room=None, migrate=True, **overrides):
         planes = planes or choose_planes(case, nranks)
         p, _, _ = capi.case_params(case)
         st, gids = capi.case_init_range(case, planes[rank], planes[rank + 1])
@@ -119,7 +119,8 @@ class SlabSim(capi.Sim):
         p.npts = n
         p.rank, p.nranks = rank, nranks
         room = halo_room if halo_room is not None else max(1 << 16, n // 8)
-        p.capacity = n + 2 * room
+        p.capacity = n + 4 * room  # growth by migration 2*room, each side's halo room
+        p.migrate = 1 if migrate else 0
         big = 1e300
         p.slab_lo = max(planes[rank], -big)
         p.slab_hi = min(planes[rank + 1], big)
@@ -133,6 +134,19 @@ class SlabSim(capi.Sim):
         sim.upload(capi.STATE_NP1, st)
         sim.upload_global_ids(gids)
         return sim
+
+    def refresh(self):
+        """After steps with migration on: the owned set (and with it the order and length of
+        the upload/download arrays) may have changed."""
+        n, self.migrated_in, self.migrated_out = self.local_count()
+        if n != self.npts or self.migrated_in or self.migrated_out:
+            self.npts = n
+            self.global_ids = self.download_global_ids()
+
+    def step(self, nsteps=1):
+        sc = super().step(nsteps)
+        self.refresh()
+        return sc
 
 
 def gather_state(sim, state, dist, group=None):

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--skin", type=float, default=0.0)
     ap.add_argument("--jitter", type=float, default=0.0)
+    ap.add_argument("--vx", type=float, default=0.0, help="initial x-velocity of the fluid")
+    ap.add_argument("--migrate", type=int, default=1)
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
 
@@ -32,7 +34,7 @@ def main():
     else:
         case = capi.default_case(spec["program"])
     over = {"skin_frac": args.skin} if args.skin > 0 else {}
-    sim = domain.SlabSim.from_case(case, rank, world, device=0, **over)
+    sim = domain.SlabSim.from_case(case, rank, world, device=0, migrate=bool(args.migrate), **over)
     tr = domain.HostTransport(rank, world)
     sim.set_transport(tr.struct)
     if args.jitter > 0:
@@ -45,17 +47,25 @@ def main():
         sim.upload(capi.STATE_N, mine, names=("x",))
         sim.upload(capi.STATE_NP1, mine, names=("x",))
 
+    if args.vx != 0.0:
+        fluid = sim.global_ids >= sim.bound_parts
+        v = np.zeros((sim.dim, sim.npts))
+        v[0, fluid] = args.vx
+        sim.upload(capi.STATE_N, {"v": v}, names=("v",))
+        sim.upload(capi.STATE_NP1, {"v": v}, names=("v",))
+
     res = {}
     sim.forces(capi.STATE_N)
     f0 = sim.download(capi.STATE_N, names=("f", "V", "Rrho"))
     offs, cols = sim.neighbours(capi.STATE_N)
+    # gathered before stepping: migration may change who owns what
+    g0 = domain.gather_state(sim, f0, dist)
+    rows = [None] * world
+    dist.all_gather_object(rows, (sim.global_ids, offs, cols))
     sim.zero_boundary_forces(capi.STATE_N)
     sc = sim.step(args.steps)
     st = sim.download(capi.STATE_N)
-    g0 = domain.gather_state(sim, f0, dist)
     g1 = domain.gather_state(sim, st, dist)
-    rows = [None] * world
-    dist.all_gather_object(rows, (sim.global_ids, offs, cols))
     if rank == 0:
         for k, a in g0.items():
             res["forces_" + k] = a
@@ -75,6 +85,10 @@ def main():
         res["scalars"] = np.array([sc["dt"], sc["t"], sc["maxmu"], sc["maxf"], sc["errsum"], sc["logbase"],
                                    float(sc["hit_pairs"]), float(sc["step_redos"]), float(sc["list_rebuilds"])])
         res["per_rank"] = np.array([len(r[0]) for r in rows])
+    moved = [None] * world
+    dist.all_gather_object(moved, (sim.npts, getattr(sim, "migrated_in", 0), getattr(sim, "migrated_out", 0)))
+    if rank == 0:
+        res["moved"] = np.array(moved)
         np.savez(args.out, **res)
     if tr.error is not None:
         raise tr.error

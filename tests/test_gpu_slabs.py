@@ -30,7 +30,7 @@ def free_port():
     return port
 
 
-def run_slabs(spec, nranks, tmp_path, steps=2, skin=0.0, jitter=0.0):
+def run_slabs(spec, nranks, tmp_path, steps=2, skin=0.0, jitter=0.0, vx=0.0, migrate=1):
     out = str(tmp_path / "slabs.npz")
     port = free_port()
     procs = []
@@ -38,7 +38,8 @@ def run_slabs(spec, nranks, tmp_path, steps=2, skin=0.0, jitter=0.0):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_RANK=str(r),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         cmd = [sys.executable, "-u", os.path.join(HERE, "slab_worker.py"), "--spec", json.dumps(spec),
-               "--steps", str(steps), "--skin", str(skin), "--jitter", str(jitter), "--out", out]
+               "--steps", str(steps), "--skin", str(skin), "--jitter", str(jitter), "--vx", str(vx),
+               "--migrate", str(migrate), "--out", out]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs, bad = [], False
     for p in procs:
@@ -54,7 +55,7 @@ def run_slabs(spec, nranks, tmp_path, steps=2, skin=0.0, jitter=0.0):
     return np.load(out)
 
 
-def oracle_run(spec, steps, jitter=0.0):
+def oracle_run(spec, steps, jitter=0.0, vx=0.0):
     oc, _ = util.both_cases(spec)
     orc = O.Oracle(oc)
     if jitter > 0:
@@ -65,6 +66,11 @@ def oracle_run(spec, steps, jitter=0.0):
         x = st["x"] + dx.T
         orc.set_state(O.STATE_N, x=x)
         orc.set_state(O.STATE_NP1, x=x)
+    if vx != 0.0:
+        v = np.zeros((orc.npts, orc.dim))
+        v[orc.bound_parts:, 0] = vx
+        orc.set_state(O.STATE_N, v=v)
+        orc.set_state(O.STATE_NP1, v=v)
     orc.forces(O.STATE_N)
     f0 = orc.get_state(O.STATE_N)
     nb = orc.neighbours(O.STATE_N)
@@ -113,3 +119,26 @@ def test_slabs_on_jittered_positions_with_a_tight_skin(tmp_path):
     orc, f0, nb = oracle_run(spec, 4, jitter=0.01)
     check(res, orc, f0, nb, "jittered block on 2 slabs")
     assert res["scalars"][8] >= 4  # rebuilds happened
+
+
+@pytest.mark.parametrize("name,nranks,vx", [("wcxsph3d_block", 3, 0.8), ("wcxsph_fine", 2, 0.9)])
+def test_particles_migrate_between_slabs(name, nranks, vx, tmp_path):
+    # the fluid drifts along x: whole lattice layers cross the planes and change owner, the
+    # tight skin makes every step rebuild its lists (migration happens at those rebuilds)
+    spec = util.small_cases()[name]
+    steps = 12
+    res = run_slabs(spec, nranks, tmp_path, steps=steps, skin=0.004, vx=vx)
+    orc, f0, nb = oracle_run(spec, steps, vx=vx)
+    check(res, orc, f0, nb, "%s drifting on %d slabs" % (name, nranks))
+    moved = res["moved"]
+    assert moved[:, 1].sum() > 0 and moved[:, 1].sum() == moved[:, 2].sum(), moved  # handed over == received
+    assert moved[:, 0].sum() == orc.npts
+    assert not np.array_equal(moved[:, 0], res["per_rank"]), "nobody changed owner"
+
+
+def test_without_migration_the_answer_is_the_same(tmp_path):
+    spec = util.small_cases()["wcxsph3d_block"]
+    res = run_slabs(spec, 2, tmp_path, steps=8, skin=0.004, vx=0.8, migrate=0)
+    orc, f0, nb = oracle_run(spec, 8, vx=0.8)
+    check(res, orc, f0, nb, "drifting block on 2 slabs, owners fixed")
+    assert res["moved"][:, 1].sum() == 0
