@@ -88,6 +88,11 @@ struct sph_ctx {
     uint32_t* need_host = nullptr; /* pinned, 8 words */
     void* tmp = nullptr; /* cap * 8 bytes staging, original order */
 
+    /* DensityReinit: dependency counters, frontier queue, control block (allocated on first use) */
+    uint32_t *ri_pend = nullptr, *ri_queue = nullptr;
+    ReinitCtl* ri_ctl = nullptr;
+    uint64_t reinit_launches = 0;
+
     uint64_t rebuilds = 0, redos = 0;
     bool uploaded_n = false, uploaded_np1 = false;
 
@@ -1181,7 +1186,8 @@ void sph_destroy(sph_ctx* c) {
     void* ptrs[] = {c->pp,   c->pp_alt, c->pRrho, c->pRrho_alt, c->id,       c->id_alt,   c->gid,     c->gid_alt, c->keys,
                     c->keys_alt, c->perm, c->perm_alt, c->hist, c->bsum,     c->cbeg,     c->cend,    c->hbeg,    c->hend,
                     c->nbr,  c->cnt,    c->need,  c->S,         c->part,     c->part2,    c->bbox_part, c->tmp,   c->send_idx,
-                    c->halo_pos, c->sendbuf, c->recvbuf, c->sendgid, c->recvgid, c->flags, c->fpos,   c->red_dev, c->drop, c->migsend, c->migrecv};
+                    c->halo_pos, c->sendbuf, c->recvbuf, c->sendgid, c->recvgid, c->flags, c->fpos,   c->red_dev, c->drop, c->migsend, c->migrecv,
+                    c->ri_pend, c->ri_queue, c->ri_ctl};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->S_host) (void)hipHostFree(c->S_host);
@@ -1381,7 +1387,52 @@ int sph_set_dt(sph_ctx* c, double dt) {
 
 int sph_density_reinit(sph_ctx* c) {
     if (!c) return SPH_EINVAL;
-    return fail(c, SPH_ESTATE, "density re-initialisation is not built yet");
+    if (!c->uploaded_np1) return fail(c, SPH_ESTATE, "state was never uploaded");
+    if (c->dist)
+        return fail(c, SPH_ESTATE, "density re-initialisation walks the particles in global index order and is not "
+                                   "available on a slab-decomposed context");
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t n = c->n;
+    if (!c->ri_pend) {
+        CHK(dalloc(c, &c->ri_pend, c->cap));
+        CHK(dalloc(c, &c->ri_queue, c->cap));
+        CHK(dalloc(c, &c->ri_ctl, 1));
+    }
+    /* complete lists (wall-wall pairs included) on the positions of state n+1 */
+    CHK(rebuild(c, c->b0));
+    Rec* r = c->rec[c->b0];
+    HIPCHK(hipMemsetAsync(c->ri_ctl, 0, sizeof(ReinitCtl), c->stream));
+#define RI(K, ...)                                                                                              \
+    do {                                                                                                        \
+        if (c->dim == 3) hipLaunchKernelGGL(K<3>, __VA_ARGS__, c->dp, r, c->nbr, c->cap_k, c->cnt, c->id,        \
+                                            c->ri_pend, c->ri_queue, c->ri_ctl);                                \
+        else hipLaunchKernelGGL(K<2>, __VA_ARGS__, c->dp, r, c->nbr, c->cap_k, c->cnt, c->id, c->ri_pend,       \
+                                c->ri_queue, c->ri_ctl);                                                        \
+    } while (0)
+    RI(k_reinit_count, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream);
+    hipLaunchKernelGGL(k_reinit_start, dim3(1), dim3(1), 0, c->stream, c->ri_ctl);
+    HIPCHK(hipGetLastError());
+    /* one launch per dependency level; the host looks at the queue every so often */
+    const int batch = 256, grid = 64;
+    ReinitCtl* h = (ReinitCtl*)c->need_host; /* pinned, 8 words */
+    for (uint64_t guard = 0;; ++guard) {
+        for (int b = 0; b < batch; ++b) RI(k_reinit_level, dim3(grid), dim3(SPH_BLOCK), 0, c->stream);
+        c->reinit_launches += batch;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (h->begin == h->end) {
+            if (h->tail != n) return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
+            break;
+        }
+        if (guard > (uint64_t)n / batch + 4) return fail(c, SPH_ESTATE, "density re-initialisation did not finish");
+    }
+#undef RI
+    /* p/rho^2 of the records follows the new rho (Forces forms it from p and rho, WCXSPH3D.cpp:180) */
+    hipLaunchKernelGGL(k_fix_prr, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, r, c->pp, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SPH_OK;
 }
 
 int sph_neighbours(sph_ctx* c, int32_t which, uint64_t* row_offsets, uint32_t* cols) {

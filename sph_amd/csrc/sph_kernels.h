@@ -1139,6 +1139,244 @@ __global__ void k_apply_global(DevParams P, DevScalars* S, double maxmu, double 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* DensityReinit (WCXSPH3D.cpp:208-249; WCXSPH.cpp:204-243; WCSPH.cpp:203-243)                  */
+/*                                                                                            */
+/* The reference walks the particles in index order and overwrites rho in place, so particle i */
+/* sees the new rho of every neighbour with a smaller index (Gauss-Seidel).  Here a particle is */
+/* released once all its smaller-index neighbours are done: the frontier of released particles  */
+/* is processed by one launch, which in turn releases the next frontier.  Same values as the    */
+/* sequential walk, in as many launches as the longest dependency chain.                       */
+
+struct ReinitCtl {
+    uint32_t begin, end; /* queue range of the frontier the next launch processes */
+    uint32_t tail;       /* end of the queue */
+    uint32_t ticket;     /* blocks of the running launch that have finished */
+};
+
+/* W2Kernel (WCXSPH3D.cpp:121-128) */
+__device__ __forceinline__ double w2_kernel(const DevParams& P, double r) {
+    const double q = r / P.H;
+    if (!(q < 2)) return 0.0;
+    const double t = 1 - 0.5 * q;
+    const double t2 = t * t;
+    return (t2 * t2) * (2 * q + 1) * P.correc;
+}
+
+/* Eigen's FullPivLU on an N x N matrix, then the solve of A*beta = e0 (WCXSPH3D.cpp:232-236):
+ * complete pivoting (first largest entry in column-major order), rank by the default
+ * threshold eps*N*|max pivot|.  All indexing is static so that the matrix stays in registers.
+ * Returns false when the matrix is not invertible by that test. */
+template <int N>
+__device__ __forceinline__ bool fullpiv_solve_e0(double (&lu)[N][N], double (&beta)[N]) {
+    int rowT[N], colT[N];
+    int nonzero = N;
+    double maxpivot = 0.0;
+    bool stopped = false;
+#pragma unroll
+    for (int kk = 0; kk < N; ++kk) {
+        rowT[kk] = kk;
+        colT[kk] = kk;
+        if (stopped) continue;
+        int br = kk, bc = kk;
+        double biggest = -1.0;
+#pragma unroll
+        for (int c = kk; c < N; ++c)
+#pragma unroll
+            for (int r = kk; r < N; ++r) {
+                const double a = fabs(lu[r][c]);
+                if (a > biggest) { biggest = a; br = r; bc = c; }
+            }
+        if (biggest == 0.0) {
+            nonzero = kk;
+            stopped = true;
+            continue;
+        }
+        if (biggest > maxpivot) maxpivot = biggest;
+        rowT[kk] = br;
+        colT[kk] = bc;
+#pragma unroll
+        for (int r = kk + 1; r < N; ++r)
+            if (r == br) {
+#pragma unroll
+                for (int c = 0; c < N; ++c) { const double t = lu[kk][c]; lu[kk][c] = lu[r][c]; lu[r][c] = t; }
+            }
+#pragma unroll
+        for (int c = kk + 1; c < N; ++c)
+            if (c == bc) {
+#pragma unroll
+                for (int r = 0; r < N; ++r) { const double t = lu[r][kk]; lu[r][kk] = lu[r][c]; lu[r][c] = t; }
+            }
+#pragma unroll
+        for (int r = kk + 1; r < N; ++r) lu[r][kk] /= lu[kk][kk];
+#pragma unroll
+        for (int r = kk + 1; r < N; ++r)
+#pragma unroll
+            for (int c = kk + 1; c < N; ++c) lu[r][c] -= lu[r][kk] * lu[kk][c];
+    }
+    const double thr = fabs(maxpivot) * (2.220446049250313e-16 * N);
+    int rank = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (i < nonzero && fabs(lu[i][i]) > thr) ++rank;
+    if (rank != N) return false;
+    double c[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) c[i] = i == 0 ? 1.0 : 0.0;
+#pragma unroll
+    for (int kk = 0; kk < N; ++kk) /* c = P*e0: the row transpositions in order */
+#pragma unroll
+        for (int r = kk + 1; r < N; ++r)
+            if (r == rowT[kk]) { const double t = c[kk]; c[kk] = c[r]; c[r] = t; }
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int cc = 0; cc < r; ++cc) c[r] -= lu[r][cc] * c[cc];
+#pragma unroll
+    for (int r = N - 1; r >= 0; --r) {
+#pragma unroll
+        for (int cc = r + 1; cc < N; ++cc) c[r] -= lu[r][cc] * c[cc];
+        c[r] /= lu[r][r];
+    }
+#pragma unroll
+    for (int kk = N - 1; kk >= 0; --kk) /* x = Q*c: the column transpositions undone */
+#pragma unroll
+        for (int r = kk + 1; r < N; ++r)
+            if (r == colT[kk]) { const double t = c[kk]; c[kk] = c[r]; c[r] = t; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) beta[i] = c[i];
+    return true;
+}
+
+/* pend[i] = number of neighbours inside the radius with a smaller original index; particles
+ * with none form the first frontier */
+template <int DIM>
+__global__ __launch_bounds__(SPH_BLOCK) void k_reinit_count(DevParams P, const Rec* __restrict__ rec,
+                                                            const uint32_t* __restrict__ nbr, uint32_t stride,
+                                                            const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
+                                                            uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
+                                                            ReinitCtl* __restrict__ ctl) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= P.n) return;
+    const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
+    const uint32_t me = id[i], c = cnt[i];
+    uint32_t lower = 0;
+    for (uint32_t k = 0; k < c; ++k) {
+        const uint32_t j = nbr[(size_t)i * stride + k];
+        const double d2 = dist2_exact(rec[j].xv[0][0] - xi, rec[j].xv[1][0] - yi, DIM == 3 ? rec[j].xv[2][0] - zi : 0.0);
+        if (d2 < P.R2 && id[j] < me) ++lower;
+    }
+    pend[i] = lower;
+    if (lower == 0) queue[atomicAdd(&ctl->tail, 1u)] = i;
+}
+
+__global__ void k_reinit_start(ReinitCtl* ctl) {
+    ctl->begin = 0;
+    ctl->end = ctl->tail;
+    ctl->ticket = 0;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(SPH_BLOCK) void k_reinit_level(DevParams P, Rec* __restrict__ rec,
+                                                            const uint32_t* __restrict__ nbr, uint32_t stride,
+                                                            const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
+                                                            uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
+                                                            ReinitCtl* __restrict__ ctl) {
+    constexpr int N = DIM + 1;
+    const uint32_t begin = ctl->begin, end = ctl->end;
+    for (uint32_t q = begin + blockIdx.x * SPH_BLOCK + threadIdx.x; q < end; q += gridDim.x * SPH_BLOCK) {
+        const uint32_t i = queue[q];
+        const Rec ri = rec[i];
+        const uint32_t me = id[i], c = cnt[i];
+        double A[N][N];
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int cc = 0; cc < N; ++cc) A[r][cc] = 0.0;
+        /* Abar accumulation (WCXSPH3D.cpp:218-229); the particle itself comes first (distance 0) */
+        auto add_A = [&](const double (&e)[N], double W, double mj, double rhoj) {
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+#pragma unroll
+                for (int cc = 0; cc < N; ++cc) {
+                    const double abar = r == 0 ? e[cc] : (cc == 0 ? e[r] : e[cc] * e[r]);
+                    A[r][cc] += W * abar * mj / rhoj;
+                }
+        };
+        {
+            double e[N];
+            e[0] = 1;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) e[d + 1] = 0.0;
+            add_A(e, w2_kernel(P, 0.0), P.xsph ? (double)ri.m : P.mass, (double)ri.rho);
+        }
+        for (uint32_t k = 0; k < c; ++k) {
+            const uint32_t j = nbr[(size_t)i * stride + k];
+            const Rec rj = rec[j];
+            double R[3];
+            R[0] = ri.xv[0][0] - rj.xv[0][0];
+            R[1] = ri.xv[1][0] - rj.xv[1][0];
+            R[2] = DIM == 3 ? ri.xv[2][0] - rj.xv[2][0] : 0.0;
+            /* membership by the search's own distance (xj - xi, as the search forms it) */
+            const double d2 = dist2_exact(rj.xv[0][0] - ri.xv[0][0], rj.xv[1][0] - ri.xv[1][0],
+                                          DIM == 3 ? rj.xv[2][0] - ri.xv[2][0] : 0.0);
+            if (!(d2 < P.R2)) continue;
+            double e[N];
+            e[0] = 1;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) e[d + 1] = R[d];
+            const double r = sqrt(DIM == 3 ? R[0] * R[0] + R[1] * R[1] + R[2] * R[2] : R[0] * R[0] + R[1] * R[1]);
+            add_A(e, w2_kernel(P, r), P.xsph ? (double)rj.m : P.mass, (double)rj.rho);
+        }
+        const double A00 = A[0][0];
+        double beta[N];
+        if (!fullpiv_solve_e0<N>(A, beta)) { /* Shepard fallback (WCXSPH3D.cpp:235-236) */
+            beta[0] = 1 / A00;
+#pragma unroll
+            for (int d = 1; d < N; ++d) beta[d] = (1 / A00) * 0.0;
+        }
+        /* rho = sum m_j W (beta . (1, Rij)) (WCXSPH3D.cpp:239-247) */
+        double rho = 0.0;
+        rho += (P.xsph ? (double)ri.m : P.mass) * w2_kernel(P, 0.0) * (DIM == 3 ? ((beta[0] + beta[1] * 0.0 + beta[2] * 0.0) + beta[N - 1] * 0.0)
+                                                                                : (beta[0] + beta[1] * 0.0 + beta[2] * 0.0));
+        for (uint32_t k = 0; k < c; ++k) {
+            const uint32_t j = nbr[(size_t)i * stride + k];
+            const Rec rj = rec[j];
+            double R[3];
+            R[0] = ri.xv[0][0] - rj.xv[0][0];
+            R[1] = ri.xv[1][0] - rj.xv[1][0];
+            R[2] = DIM == 3 ? ri.xv[2][0] - rj.xv[2][0] : 0.0;
+            const double d2 = dist2_exact(rj.xv[0][0] - ri.xv[0][0], rj.xv[1][0] - ri.xv[1][0],
+                                          DIM == 3 ? rj.xv[2][0] - ri.xv[2][0] : 0.0);
+            if (!(d2 < P.R2)) continue;
+            double poly = beta[0] + beta[1] * R[0] + beta[2] * R[1];
+            if (DIM == 3) poly = poly + beta[N - 1] * R[2];
+            const double r = sqrt(DIM == 3 ? R[0] * R[0] + R[1] * R[1] + R[2] * R[2] : R[0] * R[0] + R[1] * R[1]);
+            rho += (P.xsph ? (double)rj.m : P.mass) * w2_kernel(P, r) * poly;
+        }
+        rec[i].rho = (float)rho;
+        /* release the neighbours that were waiting for this particle */
+        for (uint32_t k = 0; k < c; ++k) {
+            const uint32_t j = nbr[(size_t)i * stride + k];
+            if (id[j] <= me) continue;
+            const double d2 = dist2_exact(rec[j].xv[0][0] - ri.xv[0][0], rec[j].xv[1][0] - ri.xv[1][0],
+                                          DIM == 3 ? rec[j].xv[2][0] - ri.xv[2][0] : 0.0);
+            if (!(d2 < P.R2)) continue;
+            if (atomicSub(&pend[j], 1u) == 1u) queue[atomicAdd(&ctl->tail, 1u)] = j;
+        }
+    }
+    /* the block that finishes last hands the next frontier to the next launch */
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&ctl->ticket, 1u) == gridDim.x - 1) {
+            ctl->ticket = 0;
+            ctl->begin = end;
+            ctl->end = __hip_atomic_load(&ctl->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* neighbour-set probe: CSR over original indices                                             */
 
 template <int DIM>
