@@ -1,0 +1,94 @@
+"""The C++ driver (sph_amd/host/sph_run) end to end on the GPU: settings file in, the
+reference's two output files out, compared with what the oracle's state gives when formatted
+the way write_settings / write_frame_data do (WCXSPH3D.cpp:381-437)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SPH_RUN = os.path.join(ROOT, "sph_amd", "host", "sph_run")
+
+
+def parse_plt(path):
+    """-> header line, list of (zone title, solution time, rows array)."""
+    zones, rows = [], None
+    with open(path) as fh:
+        header = fh.readline().strip()
+        for line in fh:
+            if line.startswith("ZONE"):
+                rows = []
+                title = line.split('"')[1]
+                t = float(line.split("SOLUTIONTIME=")[1].split(",")[0])
+                zones.append((title, t, rows, line.strip()))
+            else:
+                rows.append([float(v) for v in line.split()])
+    return header, [(a, b, np.array(c), d) for a, b, c, d in zones]
+
+
+def oracle_rows(orc, which):
+    st = orc.get_state(which)
+    v = np.sqrt((st["v"] ** 2).sum(axis=1))
+    f = np.sqrt((st["f"] ** 2).sum(axis=1))
+    return np.column_stack([st["x"], v, f, st["rho"].astype(np.float64), st["p"].astype(np.float64)])
+
+
+@pytest.mark.parametrize("program,name,dim", [("WCXSPH3D", "wcxsph3d_block", 3), ("WCSPH", "wcsph_fine", 2)])
+def test_driver_writes_the_reference_outputs(program, name, dim, tmp_path):
+    assert os.path.exists(SPH_RUN), "sph_run is not built (__graft_entry__.build())"
+    spec = util.small_cases()[name]
+    nframes, npframe = 2, 10
+    settings = tmp_path / "in.txt"
+    fmt = lambda a: " ".join(repr(float(v)) for v in a)
+    settings.write_text("\n".join([
+        "default_params? no", "outfile %s" % (tmp_path / "Run"), "program %s" % program,
+        "nframes %d" % nframes, "npframe %d" % npframe, "dt 0.0002", "psize %r" % spec["pstep"],
+        "rho_ref 1000", "viscosity 0.025", "gravity 9.81", "simtype Box",
+        "npart " + " ".join(str(v) for v in spec["npart"]), "box " + fmt(spec["box"]), "start " + fmt(spec["start"]),
+        "reinit 1", ""]))
+    r = subprocess.run([SPH_RUN, str(settings)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Frame Number: 1\tError:" in r.stdout and "Simulation complete." in r.stdout
+
+    oc, _ = util.both_cases(spec)
+    orc = O.Oracle(oc)
+    orc.forces(O.STATE_N)
+    orc.zero_boundary_f(O.STATE_N)
+    k = O.derive(oc)
+
+    text = (tmp_path / "Run_Settings.txt").read_text().splitlines()
+    assert text[0] == "SIMULATION PARAMETERS:" and len(text) == 12
+    assert text[1] == "\tNumber of frames (%d)" % nframes and text[2] == "\tSteps per frame (%d)" % npframe
+    assert text[9] == "\tNumber of boundary points (%d)" % k.bound_parts
+    assert text[10] == "\tNumber of simulation points (%d)" % (k.npts - k.bound_parts)
+    assert text[11] == "\tIntegrator type (Newmark_Beta)"
+    assert abs(float(text[7].split("(")[1].rstrip(")")) - k.H) <= 1e-5 * k.H  # default stream precision: 6 digits
+
+    header, zones = parse_plt(str(tmp_path / "Run.plt"))
+    assert header == ("VARIABLES = x, y, z, V, F, rho, P" if dim == 3 else "VARIABLES = x, y, V, F, rho, P")
+    assert len(zones) == 2 * (nframes + 1)
+    frames = [oracle_rows(orc, O.STATE_N)]
+    times = [0.0]
+    for _ in range(nframes):
+        orc.step(npframe)
+        orc.density_reinit()
+        frames.append(oracle_rows(orc, O.STATE_NP1))
+        times.append(orc.scalars()["t"])
+    for fi, want in enumerate(frames):
+        (tb, timeb, rb, lineb), (tp, timep, rp, linep) = zones[2 * fi], zones[2 * fi + 1]
+        assert tb == "Boundary Data" and tp == "Particle Data"
+        assert "STRANDID=1" in lineb and "STRANDID=2" in linep
+        assert ("DATAPACKING=POINT" in linep) == (program == "WCSPH")
+        assert abs(timeb - times[fi]) <= 5.1e-4 and timeb == timep
+        got = np.vstack([rb, rp])
+        assert got.shape == want.shape and len(rb) == k.bound_parts
+        # three decimals, fixed: each printed value is the oracle's value rounded there
+        assert np.all(np.abs(got - want) <= 0.5e-3 + 1e-9 * np.maximum(1.0, np.abs(want))), fi
+        assert np.mean(np.abs(got - np.round(want, 3)) < 1e-9) > 0.999
