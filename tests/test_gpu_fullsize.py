@@ -102,3 +102,65 @@ def test_fullsize_neighbour_counts_do_not_depend_on_knobs(big):
         assert np.max(np.abs(ga[k] - gb[k])) <= 1e-10 * scale, k
     assert np.max(np.abs(ga["rho"].astype(np.float64) - gb["rho"])) <= 2e-4  # a few float ulp of 1000
     other.close()
+
+
+# ---- 2-D WCSPH at ~1 M particles (single mass, no XSPH, radius^2 = 4 H^2 + 0.001 H) -------------
+
+def dam_break_2d():
+    pstep = 0.003
+    return capi.make_case(capi.PROGRAM_WCSPH, (833, 1267), pstep, (15.0, 8.0), (0.31, 0.31))
+
+
+def test_wcsph_million_particles_known_answers_and_knob_independence():
+    case = dam_break_2d()
+    p, st0 = capi.case_init(case)
+    dt = 0.3 * p.H / p.Cs
+    case.dt0 = dt
+    sim = capi.Sim.from_case(case)
+    assert sim.npts > 1_000_000
+    nb = sim.bound_parts
+    sim.forces(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    st = sim.download(capi.STATE_N, names=("f", "Rrho"))
+    assert not st["f"][:, :nb].any() and not st["f"][0].any() and np.all(st["f"][1, nb:] == -9.81)
+    assert not st["Rrho"].any() and sim.scalars()["maxmu"] == 0.0
+
+    offs = np.zeros(sim.npts + 1, np.uint64)
+    sim._chk(capi.lib().sph_neighbours(sim._h, capi.STATE_N, offs.ctypes.data, None), "sph_neighbours")
+    counts = np.diff(offs.astype(np.int64))
+    assert (int(offs[-1]) - sim.npts) % 2 == 0 and counts.min() >= 1
+    # interior stencil: radius^2 = 4 H^2 + 0.001 H (WCSPH.cpp:96) does not scale with pstep; at
+    # pstep 0.003 it is (2.04 pstep)^2, which takes in (+-2,0) and (0,+-2): 13 points, not the 9
+    # of the program as shipped
+    assert np.bincount(counts[nb:]).argmax() == 13
+
+    sc = sim.sweeps(1)
+    g = -9.81
+    beta = np.float32(0.25)
+    c1 = 0.5 * (dt * dt) * float(np.float32(1) - np.float32(2) * beta)
+    c2 = dt * dt * float(beta)
+    s1 = sim.download(capi.STATE_NP1, names=("x", "v", "rho", "p"))
+    assert np.all(s1["v"][1, nb:] == 0.0 + 0.5 * dt * (g + g)) and not s1["v"][0].any()
+    assert np.all(s1["x"][1, nb:] == st0["x"][1, nb:] + dt * 0.0 + c1 * g + c2 * g)
+    assert np.array_equal(s1["x"][0], st0["x"][0])
+    assert np.all(s1["rho"] == np.float32(1000.0)) and not s1["p"].any()
+
+    os.environ["SPH_BRICK_LOG2"] = "2"
+    try:
+        other = capi.Sim.from_case(case, skin_frac=0.04, max_neighbours=16)
+    finally:
+        del os.environ["SPH_BRICK_LOG2"]
+    sim.upload(capi.STATE_NP1, st0)
+    for s in (sim, other):
+        s.set_dt(dt)
+        s.forces(capi.STATE_N)
+        s.zero_boundary_forces(capi.STATE_N)
+    a, b = sim.step(3), other.step(3)
+    assert a["hit_pairs"] == b["hit_pairs"] and abs(a["dt"] - b["dt"]) <= 1e-12 * a["dt"]
+    ga = sim.download(capi.STATE_NP1, names=("x", "v", "f"))
+    gb = other.download(capi.STATE_NP1, names=("x", "v", "f"))
+    for k in ("x", "v", "f"):
+        assert np.isfinite(ga[k]).all()
+        assert np.max(np.abs(ga[k] - gb[k])) <= 1e-10 * np.max(np.abs(ga[k])), k
+    sim.close()
+    other.close()
