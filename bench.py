@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--fluid", type=str, default="640x320x48", help="fluid block per GPU, NXxNYxNZ")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--skin", type=float, default=0.0, help="tuning: candidate-list skin fraction (0 = library default)")
+    ap.add_argument("--inner", type=float, default=0.0, help="tuning: working-list skin fraction (0 = default, <0 = off)")
     args = ap.parse_args()
 
     import torch
@@ -108,7 +110,7 @@ def main():
 
     case = dam_break_3d(nx, ny, nz)
     t_setup = time.perf_counter()
-    sim = capi.Sim.from_case(case, device=local_rank)
+    sim = capi.Sim.from_case(case, device=local_rank, skin_frac=args.skin, inner_skin_frac=args.inner)
     sim.forces(capi.STATE_N)            # main(): Forces at t=0, wall f zeroed
     sim.zero_boundary_forces(capi.STATE_N)
     n = sim.npts

@@ -77,6 +77,10 @@ typedef struct sph_params {
     double   slab_lo, slab_hi;
     int32_t  migrate;
     int32_t  reserved_;
+    /* Implementation knob, off at 0: with a value > 0 (e.g. 0.025) the first sweep of a step
+     * writes out the candidates within search radius * (1 + value) and the other sweeps walk
+     * only those; a step whose particles outrun that margin is redone on the full lists. */
+    double   inner_skin_frac;
 } sph_params;
 
 /* Caller-owned host arrays in ORIGINAL particle order, one array per component

@@ -40,7 +40,7 @@ class Params(C.Structure):
                 ("max_neighbours", C.c_int32), ("device", C.c_int32),
                 ("rank", C.c_int32), ("nranks", C.c_int32), ("npts_global", C.c_uint64),
                 ("capacity", C.c_uint64), ("slab_lo", C.c_double), ("slab_hi", C.c_double),
-                ("migrate", C.c_int32), ("reserved_", C.c_int32)]
+                ("migrate", C.c_int32), ("reserved_", C.c_int32), ("inner_skin_frac", C.c_double)]
 
 
 class Fields(C.Structure):

@@ -71,6 +71,13 @@ struct sph_ctx {
     uint32_t* nbr = nullptr;
     uint32_t cap_k = 0;
     uint32_t* cnt = nullptr;
+    /* the step's working lists (a subset of the candidate lists, drawn at the step's start) */
+    uint32_t* nbr_in = nullptr;
+    uint32_t nbr_in_cap_k = 0;
+    uint32_t* cnt_in = nullptr;
+    double inner_frac = 0.0, r_in2 = 0, limit_in = 0, outer_budget = 0; /* working lists are opt-in */
+    const uint32_t* use_nbr = nullptr; /* what the pair kernel walks in the step under way */
+    const uint32_t* use_cnt = nullptr;
     uint32_t* need = nullptr;
     GridParams grid;
     bool list_valid = false;
@@ -732,9 +739,21 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
 
     c->r_list2 = r_list * r_list;
     c->disp_limit = 0.5 * (r_list - std::sqrt(c->prm.search_radius_sq)) * 0.999;
+    {
+        /* working lists: radius R*(1+inner_frac), never beyond the candidate radius */
+        const double R = std::sqrt(c->prm.search_radius_sq);
+        const double r_in = std::min(R * (1.0 + c->inner_frac), r_list);
+        c->r_in2 = r_in * r_in;
+        c->limit_in = 0.5 * (r_in - R) * 0.999;
+        /* a pair within r_in now was within r_list when the candidates were listed as long as
+         * both have travelled at most this far since */
+        c->outer_budget = 0.5 * (r_list - r_in) * 0.999;
+    }
     const uint32_t wall_below = (for_step && c->dp.bound_parts > 0 && walls_move == 0.0) ? c->dp.bound_parts : 0u;
     CHK(build_lists(c, c->rec[src], wall_below));
     c->lists_for_step = for_step;
+    c->use_nbr = c->nbr;
+    c->use_cnt = c->cnt;
 
     /* travel bound restarts */
     const double z[2] = {0.0, c->disp_limit};
@@ -772,23 +791,33 @@ NState n_state(sph_ctx* c) {
 
 /* Launches the pair kernel over particles [first, first+count); its workgroups leave their
  * partials in slots [part_base, part_base + grid) of each field of c->part. */
-template <bool FUSED>
+template <bool FUSED, bool FILTER = false>
 int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out, int zero_wall, uint32_t first,
                 uint32_t count, uint32_t part_base, uint32_t part_n) {
     if (count == 0) return SPH_OK;
     NState ns = n_state(c);
     dim3 g(pairblocks(count)), b(SPH_BLOCK);
     static const int dbg = getenv("SPH_DBG") ? atoi(getenv("SPH_DBG")) : 0; /* timing experiments only */
-#define LP(D, X)                                                                                                \
-    hipLaunchKernelGGL((k_pair<D, X, FUSED>), g, b, 0, c->stream, c->dp, rin, c->nbr, c->cap_k, c->cnt, o,      \
-                       store_out, zero_wall, ns, wall_ids(c), rout, c->pp, c->S, c->part, dbg, first, count,    \
-                       part_base, part_n)
+    /* FILTER: walk the candidate lists and write the step's working lists */
+    const uint32_t* walk = FILTER ? c->nbr : c->use_nbr;
+    const uint32_t* walk_cnt = FILTER ? c->cnt : c->use_cnt;
+#define LP(D, X)                                                                                                   \
+    hipLaunchKernelGGL((k_pair<D, X, FUSED, FILTER>), g, b, 0, c->stream, c->dp, rin, walk, c->cap_k, walk_cnt, o, \
+                       store_out, zero_wall, ns, wall_ids(c), rout, c->pp, c->S, c->part, dbg, first, count,       \
+                       part_base, part_n, c->nbr_in, c->cnt_in, c->r_in2)
     if (c->dim == 3) LP(3, true);
     else if (c->xsph) LP(2, true);
     else LP(2, false);
 #undef LP
     HIPCHK(hipGetLastError());
     return SPH_OK;
+}
+
+/* the fused sweep launch; `filter` on a step's first sweep when working lists are in use */
+int launch_sweep(sph_ctx* c, bool filter, const Rec* rin, Rec* rout, OutState o, int store_out, uint32_t first,
+                 uint32_t count, uint32_t part_base, uint32_t part_n) {
+    if (filter) return launch_pair<true, true>(c, rin, rout, o, store_out, 1, first, count, part_base, part_n);
+    return launch_pair<true, false>(c, rin, rout, o, store_out, 1, first, count, part_base, part_n);
 }
 
 int pack_n_into(sph_ctx* c, Rec* dst) {
@@ -831,19 +860,19 @@ void fill_scalars(sph_ctx* c, sph_scalars* out) {
 /* One sweep's pair/update launches.  A single domain is one launch.  A slab first does the
  * layers next to its neighbours, hands their new records to the transport on the
  * communication stream, and computes its interior while they travel. */
-int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, uint32_t* part_n_out) {
+int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, bool filter, uint32_t* part_n_out) {
     const uint32_t n = c->n;
     OutState o = out_state(c, SPH_STATE_NP1);
     if (!c->dist) {
         *part_n_out = pairblocks(n);
-        return launch_pair<true>(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 1, 0, n, 0, *part_n_out);
+        return launch_sweep(c, filter, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 0, n, 0, *part_n_out);
     }
     const uint32_t nL = c->iL_end, nR = n - c->iR_begin, nI = c->iR_begin - c->iL_end;
     const uint32_t bL = nL ? pairblocks(nL) : 0, bR = nR ? pairblocks(nR) : 0, bI = nI ? pairblocks(nI) : 0;
     const uint32_t part_n = bL + bR + bI;
     *part_n_out = part_n;
-    CHK(launch_pair<true>(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 1, 0, nL, 0, part_n));
-    CHK(launch_pair<true>(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 1, c->iR_begin, nR, bL, part_n));
+    CHK(launch_sweep(c, filter, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 0, nL, 0, part_n));
+    CHK(launch_sweep(c, filter, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, c->iR_begin, nR, bL, part_n));
     const size_t hc = c->halo_cap;
     for (int side = 0; side < 2; ++side)
         if (c->nsend[side])
@@ -851,7 +880,7 @@ int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, uint32_t* part_n_out
                                c->send_idx + side * hc, c->nsend[side], c->sendbuf + side * hc);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_packed, c->stream));
-    CHK(launch_pair<true>(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 1, c->iL_end, nI, bL + bR, part_n));
+    CHK(launch_sweep(c, filter, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, c->iL_end, nI, bL + bR, part_n));
     /* the exchange runs beside the interior launch */
     HIPCHK(hipStreamWaitEvent(c->comm, c->ev_packed, 0));
     CHK(exchange_bytes(c, c->sendbuf, (size_t)c->nsend[0] * sizeof(Rec), c->recvbuf, (size_t)c->nrecv[0] * sizeof(Rec),
@@ -879,8 +908,24 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
     for (int mode = 0;; ++mode) {
         /* mode 0: keep the lists if the travel budget allows; 1: fresh lists at the step's
          * start; 2: fresh lists before every sweep (exact for any motion) */
-        if (mode >= 1 || !c->list_valid || !c->lists_for_step || !(c->disp_host <= 0.5 * c->disp_limit))
+        const bool inner = mode == 0 && c->inner_frac > 0;
+        if (mode >= 1 || !c->list_valid || !c->lists_for_step ||
+            !(c->disp_host <= (inner ? c->outer_budget : 0.5 * c->disp_limit)))
             CHK(rebuild(c, c->b0, true, true));
+        c->use_nbr = c->nbr;
+        c->use_cnt = c->cnt;
+        if (inner) {
+            /* room for the step's working lists, which the first sweep draws from the candidates */
+            if (!c->nbr_in || c->nbr_in_cap_k != c->cap_k) {
+                if (c->nbr_in) HIPCHK(hipFree(c->nbr_in));
+                c->nbr_in = nullptr;
+                CHK(dalloc(c, &c->nbr_in, (size_t)c->cap_k * c->own_cap));
+                c->nbr_in_cap_k = c->cap_k;
+                if (!c->cnt_in) CHK(dalloc(c, &c->cnt_in, c->cap));
+            }
+            const double z[2] = {0.0, c->limit_in};
+            HIPCHK(hipMemcpyAsync(&c->S->disp_in, z, sizeof z, hipMemcpyHostToDevice, c->stream));
+        }
         hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, c->stream, c->S);
         cur = c->b0;
         for (int k = 0; k < nsweeps; ++k) {
@@ -904,12 +949,16 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
                 HIPCHK(hipEventRecord(ev->a, c->stream));
             }
             uint32_t part_n = 0;
-            CHK(sweep_launches(c, cur, nxt, last, &part_n));
+            CHK(sweep_launches(c, cur, nxt, last, inner && k == 0, &part_n));
+            if (inner && k == 0) { /* the first sweep has written the step's working lists */
+                c->use_nbr = c->nbr_in;
+                c->use_cnt = c->cnt_in;
+            }
             if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
             hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS), dim3(SPH_BLOCK), 0, c->stream, c->part, part_n, PART_FIELDS,
                                c->part2);
             hipLaunchKernelGGL(k_sweep_finalize, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->part2, k,
-                               (last && !partial) ? 1 : (last ? 2 : 0), mode < 2 ? 1 : 0);
+                               (last && !partial) ? 1 : (last ? 2 : 0), mode == 2 ? 0 : (inner ? 2 : 1));
             cur = nxt;
         }
         CommitArgs a;
@@ -963,6 +1012,8 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
         break;
     }
     c->b0 = cur;
+    c->use_nbr = c->nbr;
+    c->use_cnt = c->cnt;
     return SPH_OK;
 }
 
@@ -1043,6 +1094,7 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     c->migrate = c->dist && p->migrate != 0;
     c->npairblocks = pairblocks(c->own_cap) + 24; /* up to three launches per sweep, each padded to 8 */
     if (p->skin_frac > 0) c->skin_frac = p->skin_frac;
+    if (p->inner_skin_frac > 0) c->inner_frac = p->inner_skin_frac;
     c->brick_log2 = c->dim == 3 ? 2u : 3u;
     if (const char* e = getenv("SPH_BRICK_LOG2")) c->brick_log2 = (uint32_t)std::min(5, std::max(0, atoi(e)));
 
@@ -1075,6 +1127,9 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     d.mass = p->mass;
     d.hvisc = 0.01 * p->HSQ;
     d.npts_d = 1.0 * (double)(c->dist ? p->npts_global : p->npts);
+    d.sqrtBgam = std::sqrt(d.Bgam);
+    d.invH = 1.0 / p->H;
+    d.gconst = 5.0 * (1.0 / p->HSQ) * p->correc;
 
     const size_t n = c->cap;
     for (int q = 0; q < 4; ++q)
@@ -1187,7 +1242,7 @@ void sph_destroy(sph_ctx* c) {
                     c->keys_alt, c->perm, c->perm_alt, c->hist, c->bsum,     c->cbeg,     c->cend,    c->hbeg,    c->hend,
                     c->nbr,  c->cnt,    c->need,  c->S,         c->part,     c->part2,    c->bbox_part, c->tmp,   c->send_idx,
                     c->halo_pos, c->sendbuf, c->recvbuf, c->sendgid, c->recvgid, c->flags, c->fpos,   c->red_dev, c->drop, c->migsend, c->migrecv,
-                    c->ri_pend, c->ri_queue, c->ri_ctl};
+                    c->ri_pend, c->ri_queue, c->ri_ctl, c->nbr_in, c->cnt_in};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->S_host) (void)hipHostFree(c->S_host);

@@ -509,6 +509,26 @@ __device__ __forceinline__ double fast_rsq(double x) {
     return y;
 }
 
+/* sqrt(x) for x >= 0 (zero or normal): x * x^(-1/2) from the hardware estimate refined once,
+ * then one correction of the root itself; within one unit in the last place.  The clamp
+ * keeps x = 0 (two particles at one point) away from 0 * inf. */
+__device__ __forceinline__ double fast_sqrt(double x) {
+    double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
+    const double e = fma(-(0.5 * x) * y, y, 0.5);
+    y = fma(y, e, y);
+    const double r = x * y;
+    return fma(fma(-r, r, x), 0.5 * y, r);
+}
+
+/* Streamed-once data (candidate rows, state n, everything written) is moved with the
+ * non-temporal hint, so that the L2 keeps what is reused: the neighbour records. */
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* p) { return __builtin_nontemporal_load(p); }
+template <typename T>
+__device__ __forceinline__ void stream_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
+
 #define PAIR_PARTICLES (SPH_BLOCK / 4)
 /* LDS transpose area: per wave four 1-KiB blocks (one per record of a quad's round); block r
  * is skewed by r*16 bytes so that the four lanes of a quad read four different 16-byte
@@ -530,16 +550,22 @@ __device__ __forceinline__ double fast_rsq(double x) {
  *
  *  FUSED: the quad then performs the wall reset, the Newmark-beta update, the Tait pressure
  *  and the position-change sum for its particle (WCXSPH3D.cpp:260-285): lane d owns
- *  component d (and writes chunk d of the new record), lane 3 owns rho, p and Rrho. */
-template <int DIM, bool XSPH, bool FUSED>
-__global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __restrict__ rin,
+ *  component d (and writes chunk d of the new record), lane 3 owns rho, p and Rrho.
+ *
+ *  FILTER: the step's working list.  Candidate lists carry a generous skin so that they
+ *  survive many steps; within one step particles move a small fraction of it.  The first
+ *  sweep of a step, which tests every candidate anyway, writes out those within a tighter
+ *  radius (same order); the other sweeps walk that shorter list. */
+template <int DIM, bool XSPH, bool FUSED, bool FILTER>
+__global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* __restrict__ rin,
                                                     const uint32_t* __restrict__ nbr, uint32_t stride,
                                                     const uint32_t* __restrict__ cnt, OutState out, int store_out,
                                                     int zero_wall, NState ns, const uint32_t* __restrict__ id,
                                                     Rec* __restrict__ rout, float* __restrict__ pout,
                                                     DevScalars* __restrict__ S, double* __restrict__ part, int dbg,
                                                     uint32_t first, uint32_t count, uint32_t part_base,
-                                                    uint32_t part_n) {
+                                                    uint32_t part_n, uint32_t* __restrict__ nbr_out,
+                                                    uint32_t* __restrict__ cnt_out, double r_in2) {
     __shared__ __attribute__((aligned(16))) char stage[(SPH_BLOCK / 64) * PAIR_LDS_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane & 3;
@@ -560,12 +586,24 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
     const double xi0 = ri.xv[0][0], xi1 = ri.xv[1][0], xi2 = ri.xv[2][0];
     const double vi0 = ri.xv[0][1], vi1 = ri.xv[1][1], vi2 = ri.xv[2][1];
     const double rho_i = (double)ri.rho;
-    const double sqrtBgam = sqrt(P.Bgam);
-    const double c_i = sqrt(P.Bgam / rho_i);
-    const double invH = 1.0 / P.H;
-    const double gconst = 5.0 * (1.0 / P.HSQ) * P.correc;
+    const double sqrtBgam = P.sqrtBgam;
+    const double c_i = sqrtBgam * fast_rsq(rho_i); /* sqrt(B*gam/rho), WCXSPH3D.cpp:172 */
+    const double invH = P.invH;
+    const double gconst = P.gconst;
 
-    const uint32_t c = active ? cnt[i] : 0u;
+    /* The candidate row of particle i: entry e at nbr[i*cap + e].  Every fourth round each
+     * lane fetches 16 bytes of it: lane q holds the four candidates of round 4u+q. */
+    const uint32_t* const row = nbr + (size_t)i * stride;
+    /* unconditional and in bounds; entries past the count are replaced where they are used */
+    const uint32_t last_group = stride - 4u;
+    auto fetch_vec = [&](uint32_t u) -> uint4 {
+        const uint32_t e = u * 16u + (uint32_t)q * 4u;
+        const u32x4_t v = stream_load((const u32x4_t*)(row + (e < last_group ? e : last_group)));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    /* the count and the head of the candidate row are requested together */
+    const uint32_t c = active ? stream_load(cnt + i) : 0u;
+    const uint4 vhead = fetch_vec(0);
     /* rounds of four candidates; the trip count is made wave-uniform */
     uint32_t rounds = (c + 3u) >> 2;
 #pragma unroll
@@ -577,17 +615,10 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
     double rr = 0.0, mumax = 0.0;
     uint32_t hits = 0;
 
-    /* The candidate row of particle i: entry e at nbr[i*cap + e].  Every fourth round each
-     * lane fetches 16 bytes of it: lane q holds the four candidates of round 4u+q. */
-    const uint32_t* const row = nbr + (size_t)i * stride;
-    /* unconditional and in bounds; entries past the count are replaced where they are used */
-    const uint32_t last_group = stride - 4u;
-    auto fetch_vec = [&](uint32_t u) -> uint4 {
-        const uint32_t e = u * 16u + (uint32_t)q * 4u;
-        return *(const uint4*)(row + (e < last_group ? e : last_group));
-    };
     /* the four pieces this lane holds of the next round's records */
     uint4 pc0, pc1, pc2, pc3;
+    uint32_t jnext = 0, kept = 0; /* FILTER: this lane's candidate of the round in flight; entries written */
+    uint32_t* const row_out = FILTER ? nbr_out + (size_t)i * stride : nullptr;
     auto load4 = [&](uint32_t j0, uint32_t j1, uint32_t j2, uint32_t j3) {
         pc0 = *(const uint4*)((const char*)(rin + j0) + 16 * q);
         pc1 = *(const uint4*)((const char*)(rin + j1) + 16 * q);
@@ -603,6 +634,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
         const uint32_t a2 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).z);           \
         const uint32_t a3 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).w);           \
         load4(e0 < c ? a0 : i, e0 + 1u < c ? a1 : i, e0 + 2u < c ? a2 : i, e0 + 3u < c ? a3 : i); \
+        if (FILTER) jnext = q == 0 ? a0 : (q == 1 ? a1 : (q == 2 ? a2 : a3));      \
     }
     char* const my_slot = wstage + lane * 16;
     auto exchange = [&]() -> Rec {
@@ -618,16 +650,22 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
         return *(const Rec*)(wstage + q * PAIR_LDS_BLOCK + q * 16 + (lane >> 2) * 64);
     };
 
-    auto pair_term = [&](uint32_t t, const Rec& rj) {
+    auto pair_term = [&](uint32_t t, const Rec& rj, uint32_t j) {
         const bool valid = t * 4u + (uint32_t)q < c;
         const double Rx = rj.xv[0][0] - xi0, Ry = rj.xv[1][0] - xi1;
         const double Rz = DIM == 3 ? rj.xv[2][0] - xi2 : 0.0;
         const double d2 = dist2_exact(Rx, Ry, Rz);
+        if (FILTER) { /* the quad appends its keepers in lane order */
+            const bool keep = valid && d2 <= r_in2;
+            const uint32_t bits = (uint32_t)(__ballot(keep) >> (lane & 60)) & 0xFu;
+            if (keep) stream_store(row_out + kept + __popc(bits & ((1u << q) - 1u)), j);
+            kept += __popc(bits);
+        }
         if (valid && d2 < P.R2) {
             ++hits;
             const double Vx = rj.xv[0][1] - vi0, Vy = rj.xv[1][1] - vi1;
             const double Vz = DIM == 3 ? rj.xv[2][1] - vi2 : 0.0;
-            const double r = sqrt(d2);
+            const double r = fast_sqrt(d2);
             const double qq = r * invH;
             double gs = 0.0, Kern = 0.0;
             if (qq < 2.0) {
@@ -681,12 +719,13 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
         const uint32_t t = u * 4u + (R);                       \
         if (t >= rounds) break;                                \
         const Rec rj = exchange();                             \
+        const uint32_t jcur = jnext;                           \
         if (t + 1 < rounds) LOAD_FROM(NEXTVEC, NEXTR, t + 1)   \
-        if (!(dbg & 2)) pair_term(t, rj);                      \
+        if (!(dbg & 2)) pair_term(t, rj, jcur);                \
     }
 
     if (rounds > 0) {
-        uint4 vcur = fetch_vec(0);
+        uint4 vcur = vhead;
         LOAD_FROM(vcur, 0, 0u)
         const uint32_t nsup = (rounds + 3u) >> 2;
         for (uint32_t u = 0; u < nsup; ++u) {
@@ -700,6 +739,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
     }
 #undef ROUND
 #undef LOAD_FROM
+
+    if (FILTER && active && q == 0) cnt_out[i] = kept;
 
     /* quad totals */
     acc0 = quad_sum(acc0); acc1 = quad_sum(acc1);
@@ -726,10 +767,10 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
     if (q >= DIM) fd = 0.0;
     if (active && store_out) {
         if (q < DIM) {
-            out.f[q][i] = fd;
-            if (XSPH) out.V[q][i] = Vd;
+            stream_store(out.f[q] + i, fd);
+            if (XSPH) stream_store(out.V[q] + i, Vd);
         } else if (q == 3) {
-            out.Rrho[i] = Rrho_f;
+            stream_store(out.Rrho + i, Rrho_f);
         }
     }
     if (FUSED) {
@@ -740,48 +781,62 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_pair(DevParams P, const Rec* __re
         const double dt2 = dt * dt;
         union { double d[2]; float f[4]; } chunk;
         if (q < DIM) {
-            const double fn = ns.f[q][i];
-            const double vn = ns.v[q][i];
-            const double adv = XSPH ? ns.V[q][i] : vn;
+            const double fn = stream_load(ns.f[q] + i);
+            const double vn = stream_load(ns.v[q] + i);
+            const double adv = XSPH ? stream_load(ns.V[q] + i) : vn;
             const double c1 = 0.5 * dt2 * P.omb;
             const double c2 = dt2 * P.beta;
-            const double xnew = ns.x[q][i] + dt * adv + c1 * fn + c2 * fd;
+            const double xnew = stream_load(ns.x[q] + i) + dt * adv + c1 * fn + c2 * fd;
             chunk.d[0] = xnew;
             chunk.d[1] = vn + hdt * (fn + fd);
             const double ex = xnew - (q == 0 ? xi0 : (q == 1 ? xi1 : xi2));
             move2 = ex * ex;
         } else if (q == 3) {
-            const float rsum = ns.Rrho[i] + Rrho_f; /* float add, as the reference */
-            const float rho_new = (float)((double)ns.rho[i] + hdt * (double)rsum);
+            const float rsum = stream_load(ns.Rrho + i) + Rrho_f; /* float add, as the reference */
+            const float rho_new = (float)((double)stream_load(ns.rho + i) + hdt * (double)rsum);
             const float p_new = (float)(P.B * tait_pow_m1((double)rho_new / P.rho0, P.gam));
             chunk.f[0] = rho_new;
             chunk.f[1] = ri.m;
             chunk.d[1] = (double)p_new / ((double)rho_new * (double)rho_new);
-            if (active) pout[i] = p_new;
+            if (active) stream_store(pout + i, p_new);
         } else { /* the unused component of a 2-D run stays zero */
             chunk.d[0] = 0.0;
             chunk.d[1] = 0.0;
         }
         if (active) {
-            double2 w;
+            f64x2_t w;
             w.x = chunk.d[0];
             w.y = chunk.d[1];
-            ((double2*)(rout + i))[q] = w;
+            stream_store((f64x2_t*)(rout + i) + q, w);
         }
         f2 = quad_sum(f2);
         move2 = quad_sum(move2);
     }
 
-    /* block reductions: max(mu), max |f|^2, max move^2, sum move^2, pair count; one lane per
-     * quad speaks for the particle */
+    /* block reductions: max(mu), max |f|^2, max move^2, sum move^2, pair count; lane 0 of each
+     * quad speaks for the particle, so the butterflies start at distance 4 */
     __shared__ double red[SPH_BLOCK / 64][5];
     const bool speak = active && q == 0;
-    const double wm = wave_max(speak ? mumax : 0.0);
+    auto quads_max = [](double v) {
+#pragma unroll
+        for (int o = 32; o >= 4; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+        return v;
+    };
+    auto quads_sum = [](double v) {
+#pragma unroll
+        for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    const double wm = quads_max(speak ? mumax : 0.0);
     if (FUSED) {
-        const double wf = wave_max(speak ? f2 : 0.0);
-        const double wv = wave_max(speak ? (move2 == move2 ? move2 : 1e300) : 0.0); /* NaN counts as huge */
-        const double ws = wave_sum(speak ? move2 : 0.0);
-        const double wh = wave_sum((double)hits);
+        const double wf = quads_max(speak ? f2 : 0.0);
+        const double wv = quads_max(speak ? (move2 == move2 ? move2 : 1e300) : 0.0); /* NaN counts as huge */
+        const double ws = quads_sum(speak ? move2 : 0.0);
+        /* hits: every lane of the quad counted its own candidates */
+        double wh = (double)hits;
+        wh += quad_perm_d<QP_XOR1>(wh);
+        wh += quad_perm_d<QP_XOR2>(wh);
+        wh = quads_sum(q == 0 ? wh : 0.0);
         if (lane == 0) {
             red[wave][0] = wm; red[wave][1] = wf; red[wave][2] = wv; red[wave][3] = ws; red[wave][4] = wh;
         }
@@ -873,9 +928,12 @@ __global__ void k_sweep_finalize(DevParams P, DevScalars* S, const double* __res
     }
     S->maxmu = maxmu;
     S->disp += sqrt(move2);
+    S->disp_in += sqrt(move2);
     /* the positions just written feed the next sweep's pair loop through lists built earlier:
-     * they are only complete while no particle has travelled more than half the skin */
-    if (guard_lists && !last && !(S->disp <= S->disp_limit)) S->violation = 1;
+     * they are only complete while no particle has travelled more than half the skin of the
+     * list in use (1: the candidate lists, 2: the step's working lists) */
+    if (guard_lists == 1 && !last && !(S->disp <= S->disp_limit)) S->violation = 1;
+    if (guard_lists == 2 && !last && !(S->disp_in <= S->limit_in)) S->violation = 1;
     if (last) {
         const double maxf = sqrt(maxf2);
         S->maxf = maxf;

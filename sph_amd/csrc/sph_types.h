@@ -29,6 +29,9 @@ struct DevParams {
     double   mass;
     double   hvisc;     /* 0.01*HSQ */
     double   npts_d;    /* 1.0*npts */
+    double   sqrtBgam;  /* sqrt(B*gam) */
+    double   invH;      /* 1/H */
+    double   gconst;    /* 5*(1/HSQ)*correc: the gradient's constant factor (WCXSPH3D.cpp:135) */
 };
 
 /* Uniform grid over the particles' bounding box. Cell edge >= candidate radius. */
@@ -53,6 +56,8 @@ struct DevScalars {
     float  t;
     int32_t violation;            /* a sweep started with disp > disp_limit */
     unsigned long long hit_pairs; /* i != j pairs inside the radius in the last finished sweep */
+    double disp_in;   /* travel bound since the step's working lists were drawn; its limit */
+    double limit_in;
 };
 
 #endif

@@ -336,3 +336,28 @@ def test_density_reinit_on_a_uniform_lattice_keeps_rho0_inside():
     rho = sim.download(capi.STATE_NP1)["rho"]
     assert np.isfinite(rho).all()
     sim.close()
+
+
+# ---- per-step working lists (opt-in knob) --------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["wcxsph3d_block", "wcxsph_fine", "wcsph_fine"])
+def test_working_lists_give_the_same_answer(name):
+    # the first sweep of each step writes the candidates within 1.025 R; the rest walk those
+    orc, sim = start(CASES[name], inner_skin_frac=0.025)
+    orc.step(10)
+    sc = sim.step(10)
+    assert_state_close(sim.download(capi.STATE_N), orc.get_state(O.STATE_N), name)
+    assert_scalars_close(sc, orc.scalars(), name)
+    sim.close()
+
+
+def test_working_lists_too_tight_fall_back_to_the_candidates():
+    # a margin far smaller than a step's motion: every step is redone on the full lists
+    orc, sim = start(CASES["wcxsph3d_block"], inner_skin_frac=1e-7)
+    orc.step(30)
+    sim.step(29)
+    before = sim.scalars()["step_redos"]
+    sc = sim.step(1)
+    assert sc["step_redos"] > before > 0
+    assert_state_close(sim.download(capi.STATE_N), orc.get_state(O.STATE_N), "tight working lists")
+    sim.close()
