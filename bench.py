@@ -142,8 +142,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": "C3: WCXSPH3D dam break, Pstep 0.1, fluid %dx%dx%d + walls, box %.1fx%.1fx%.1f"
-                        % (nx, ny, nz, case.box[0], case.box[1], case.box[2]),
+            "workload": "%s: WCXSPH3D dam break, Pstep 0.1, fluid %dx%dx%d + walls, box %.1fx%.1fx%.1f"
+                        % ({(640, 320, 48): "C3", (2048, 1024, 48): "C4 on one GPU"}.get((nx, ny, nz), "custom size"),
+                           nx, ny, nz, case.box[0], case.box[1], case.box[2]),
             "particles": n, "wall_particles": sim.bound_parts, "sweeps_per_step": 8,
             "force_evals_per_s": value * 8,
             "pairs_in_radius_per_particle": (sc["hit_pairs"] + n) / n,
