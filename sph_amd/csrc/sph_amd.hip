@@ -260,6 +260,7 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
         HIPCHK(hipFree(c->nbr));
         c->nbr = nullptr;
         CHK(dalloc(c, &c->nbr, (size_t)newcap * c->own_cap));
+        HIPCHK(hipMemsetAsync(c->nbr, 0, sizeof(uint32_t) * (size_t)newcap * c->own_cap, c->stream));
         c->cap_k = newcap;
     }
     return fail(c, SPH_ESTATE, "candidate lists kept overflowing");
@@ -801,13 +802,15 @@ int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out
     /* FILTER: walk the candidate lists and write the step's working lists */
     const uint32_t* walk = FILTER ? c->nbr : c->use_nbr;
     const uint32_t* walk_cnt = FILTER ? c->cnt : c->use_cnt;
-#define LP(D, X)                                                                                                   \
-    hipLaunchKernelGGL((k_pair<D, X, FUSED, FILTER>), g, b, 0, c->stream, c->dp, rin, walk, c->cap_k, walk_cnt, o, \
-                       store_out, zero_wall, ns, wall_ids(c), rout, c->pp, c->S, c->part, dbg, first, count,       \
+    /* record arrays of 4 GiB and more need 64-bit piece addresses */
+    const bool wide = (uint64_t)c->cap * sizeof(Rec) >= (1ull << 32);
+#define LP(D, X, W)                                                                                                   \
+    hipLaunchKernelGGL((k_pair<D, X, FUSED, FILTER, W>), g, b, 0, c->stream, c->dp, rin, walk, c->cap_k, walk_cnt, o, \
+                       store_out, zero_wall, ns, wall_ids(c), rout, c->pp, c->S, c->part, dbg, first, count,          \
                        part_base, part_n, c->nbr_in, c->cnt_in, c->r_in2)
-    if (c->dim == 3) LP(3, true);
-    else if (c->xsph) LP(2, true);
-    else LP(2, false);
+    if (c->dim == 3) { if (wide) LP(3, true, true); else LP(3, true, false); }
+    else if (c->xsph) { if (wide) LP(2, true, true); else LP(2, true, false); }
+    else { if (wide) LP(2, false, true); else LP(2, false, false); }
 #undef LP
     HIPCHK(hipGetLastError());
     return SPH_OK;
@@ -920,6 +923,7 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
                 if (c->nbr_in) HIPCHK(hipFree(c->nbr_in));
                 c->nbr_in = nullptr;
                 CHK(dalloc(c, &c->nbr_in, (size_t)c->cap_k * c->own_cap));
+                HIPCHK(hipMemsetAsync(c->nbr_in, 0, sizeof(uint32_t) * (size_t)c->cap_k * c->own_cap, c->stream));
                 c->nbr_in_cap_k = c->cap_k;
                 if (!c->cnt_in) CHK(dalloc(c, &c->cnt_in, c->cap));
             }
@@ -1174,6 +1178,8 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     c->cap_k = p->max_neighbours > 0 ? (uint32_t)p->max_neighbours : (c->dim == 3 ? 96u : 40u);
     c->cap_k = (c->cap_k + 3u) & ~3u;
     CHK(dalloc(c, &c->nbr, (size_t)c->cap_k * c->own_cap));
+    /* the pair kernel fetches whole groups of a row: every entry, used or not, must index the arrays */
+    HIPCHK(hipMemsetAsync(c->nbr, 0, sizeof(uint32_t) * (size_t)c->cap_k * c->own_cap, c->stream));
     CHK(dalloc(c, &c->cnt, n));
     CHK(dalloc(c, &c->need, 8));
     CHK(dalloc(c, &c->S, 1));
@@ -1692,5 +1698,16 @@ int sph_use_rccl(sph_ctx* c, const void* unique_id_128) {
     c->have_tr = true;
     return SPH_OK;
 }
+
+#ifdef SPH_PHASE_TIMING
+int sph_debug_read_phases(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 }  /* extern "C" */

@@ -529,6 +529,13 @@ __device__ __forceinline__ T stream_load(const T* p) { return __builtin_nontempo
 template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
 
+#ifdef SPH_PHASE_TIMING /* development builds only: where a wave of the pair kernel spends its cycles */
+__device__ unsigned long long g_phase[8];
+#define PHASE_MARK(k) const unsigned long long tmark##k = __builtin_amdgcn_s_memtime();
+#else
+#define PHASE_MARK(k)
+#endif
+
 #define PAIR_PARTICLES (SPH_BLOCK / 4)
 /* LDS transpose area: per wave four 1-KiB blocks (one per record of a quad's round); block r
  * is skewed by r*16 bytes so that the four lanes of a quad read four different 16-byte
@@ -556,7 +563,7 @@ __device__ __forceinline__ void stream_store(T* p, T v) { __builtin_nontemporal_
  *  survive many steps; within one step particles move a small fraction of it.  The first
  *  sweep of a step, which tests every candidate anyway, writes out those within a tighter
  *  radius (same order); the other sweeps walk that shorter list. */
-template <int DIM, bool XSPH, bool FUSED, bool FILTER>
+template <int DIM, bool XSPH, bool FUSED, bool FILTER, bool WIDE>
 __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* __restrict__ rin,
                                                     const uint32_t* __restrict__ nbr, uint32_t stride,
                                                     const uint32_t* __restrict__ cnt, OutState out, int store_out,
@@ -567,6 +574,7 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* _
                                                     uint32_t part_n, uint32_t* __restrict__ nbr_out,
                                                     uint32_t* __restrict__ cnt_out, double r_in2) {
     __shared__ __attribute__((aligned(16))) char stage[(SPH_BLOCK / 64) * PAIR_LDS_WAVE];
+    PHASE_MARK(0)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane & 3;
     /* Workgroups are dealt round-robin to the eight XCDs, each with its own L2.  Give every
@@ -619,7 +627,18 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* _
     uint4 pc0, pc1, pc2, pc3;
     uint32_t jnext = 0, kept = 0; /* FILTER: this lane's candidate of the round in flight; entries written */
     uint32_t* const row_out = FILTER ? nbr_out + (size_t)i * stride : nullptr;
+    /* While the record array is smaller than 4 GiB (!WIDE) a 32-bit byte offset from its base
+     * addresses any piece: one shift-or per load instead of 64-bit arithmetic. */
+    const uint32_t qoff = 16u * (uint32_t)q;
     auto load4 = [&](uint32_t j0, uint32_t j1, uint32_t j2, uint32_t j3) {
+        if (!WIDE) {
+            const char* const base = (const char*)rin;
+            pc0 = *(const uint4*)(base + ((j0 << 6) | qoff));
+            pc1 = *(const uint4*)(base + ((j1 << 6) | qoff));
+            pc2 = *(const uint4*)(base + ((j2 << 6) | qoff));
+            pc3 = *(const uint4*)(base + ((j3 << 6) | qoff));
+            return;
+        }
         pc0 = *(const uint4*)((const char*)(rin + j0) + 16 * q);
         pc1 = *(const uint4*)((const char*)(rin + j1) + 16 * q);
         pc2 = *(const uint4*)((const char*)(rin + j2) + 16 * q);
@@ -633,7 +652,9 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* _
         const uint32_t a1 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).y);           \
         const uint32_t a2 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).z);           \
         const uint32_t a3 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).w);           \
-        load4(e0 < c ? a0 : i, e0 + 1u < c ? a1 : i, e0 + 2u < c ? a2 : i, e0 + 3u < c ? a3 : i); \
+        /* entries past the count are stale or zero but always index the arrays (the lists are  \
+         * cleared when allocated); what is fetched for them is never used */                   \
+        load4(a0, a1, a2, a3);                                                                  \
         if (FILTER) jnext = q == 0 ? a0 : (q == 1 ? a1 : (q == 2 ? a2 : a3));      \
     }
     char* const my_slot = wstage + lane * 16;
@@ -724,6 +745,7 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* _
         if (!(dbg & 2)) pair_term(t, rj, jcur);                \
     }
 
+    PHASE_MARK(1)
     if (rounds > 0) {
         uint4 vcur = vhead;
         LOAD_FROM(vcur, 0, 0u)
@@ -739,6 +761,7 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* _
     }
 #undef ROUND
 #undef LOAD_FROM
+    PHASE_MARK(2)
 
     if (FILTER && active && q == 0) cnt_out[i] = kept;
 
@@ -813,6 +836,7 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* _
         move2 = quad_sum(move2);
     }
 
+    PHASE_MARK(3)
     /* block reductions: max(mu), max |f|^2, max move^2, sum move^2, pair count; lane 0 of each
      * quad speaks for the particle, so the butterflies start at distance 4 */
     __shared__ double red[SPH_BLOCK / 64][5];
@@ -866,6 +890,17 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* _
             part[4 * (size_t)nb + block] = h;
         }
     }
+#ifdef SPH_PHASE_TIMING
+    if (FUSED && (blockIdx.x & 63u) == 0 && lane == 0 && rounds >= 7) { /* fluid waves */
+        const unsigned long long tend = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_phase[0], tmark1 - tmark0);
+        atomicAdd(&g_phase[1], tmark2 - tmark1);
+        atomicAdd(&g_phase[2], tmark3 - tmark2);
+        atomicAdd(&g_phase[3], tend - tmark3);
+        atomicAdd(&g_phase[4], (unsigned long long)rounds);
+        atomicAdd(&g_phase[7], 1ull);
+    }
+#endif
 }
 
 /* ------------------------------------------------------------------------------------------ */
