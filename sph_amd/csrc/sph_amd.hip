@@ -82,7 +82,7 @@ struct sph_ctx {
     GridParams grid;
     bool list_valid = false;
     bool lists_for_step = false; /* built by the stepping path (wall-wall pairs may be left out) */
-    double skin_frac = 0.1, r_list2 = 0, disp_limit = 0;
+    double skin_frac = 0.05, r_list2 = 0, disp_limit = 0;
     uint32_t brick_log2 = 2;
     double disp_host = 0;
 
@@ -797,7 +797,7 @@ int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out
                 uint32_t count, uint32_t part_base, uint32_t part_n) {
     if (count == 0) return SPH_OK;
     NState ns = n_state(c);
-    dim3 g(pairblocks(count)), b(SPH_BLOCK);
+    dim3 g(pairblocks(count)), b(PAIR_BLOCK);
     static const int dbg = getenv("SPH_DBG") ? atoi(getenv("SPH_DBG")) : 0; /* timing experiments only */
     /* FILTER: walk the candidate lists and write the step's working lists */
     const uint32_t* walk = FILTER ? c->nbr : c->use_nbr;

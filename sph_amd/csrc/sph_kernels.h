@@ -536,7 +536,10 @@ __device__ unsigned long long g_phase[8];
 #define PHASE_MARK(k)
 #endif
 
-#define PAIR_PARTICLES (SPH_BLOCK / 4)
+#ifndef PAIR_BLOCK
+#define PAIR_BLOCK 256 /* threads per workgroup of the pair kernel */
+#endif
+#define PAIR_PARTICLES (PAIR_BLOCK / 4)
 /* LDS transpose area: per wave four 1-KiB blocks (one per record of a quad's round); block r
  * is skewed by r*16 bytes so that the four lanes of a quad read four different 16-byte
  * bank groups */
@@ -564,7 +567,7 @@ __device__ unsigned long long g_phase[8];
  *  sweep of a step, which tests every candidate anyway, writes out those within a tighter
  *  radius (same order); the other sweeps walk that shorter list. */
 template <int DIM, bool XSPH, bool FUSED, bool FILTER, bool WIDE>
-__global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* __restrict__ rin,
+__global__ __launch_bounds__(PAIR_BLOCK, 4) void k_pair(DevParams P, const Rec* __restrict__ rin,
                                                     const uint32_t* __restrict__ nbr, uint32_t stride,
                                                     const uint32_t* __restrict__ cnt, OutState out, int store_out,
                                                     int zero_wall, NState ns, const uint32_t* __restrict__ id,
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* _
                                                     uint32_t first, uint32_t count, uint32_t part_base,
                                                     uint32_t part_n, uint32_t* __restrict__ nbr_out,
                                                     uint32_t* __restrict__ cnt_out, double r_in2) {
-    __shared__ __attribute__((aligned(16))) char stage[(SPH_BLOCK / 64) * PAIR_LDS_WAVE];
+    __shared__ __attribute__((aligned(16))) char stage[(PAIR_BLOCK / 64) * PAIR_LDS_WAVE];
     PHASE_MARK(0)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane & 3;
@@ -609,9 +612,23 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* _
         const u32x4_t v = stream_load((const u32x4_t*)(row + (e < last_group ? e : last_group)));
         return make_uint4(v.x, v.y, v.z, v.w);
     };
-    /* the count and the head of the candidate row are requested together */
+    /* the count and the head of the candidate row are requested together, and with them
+     * (FUSED) this lane's share of state n, which only the update after the pair loop reads:
+     * one trip to HBM for all of it instead of a second one after the loop */
     const uint32_t c = active ? stream_load(cnt + i) : 0u;
     const uint4 vhead = fetch_vec(0);
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+    if (FUSED) {
+        if (q < DIM) {
+            n0 = stream_load(ns.f[q] + i);
+            n1 = stream_load(ns.v[q] + i);
+            n2 = XSPH ? stream_load(ns.V[q] + i) : 0.0;
+            n3 = stream_load(ns.x[q] + i);
+        } else if (q == 3) {
+            n0 = (double)stream_load(ns.Rrho + i); /* floats travel exactly through double */
+            n1 = (double)stream_load(ns.rho + i);
+        }
+    }
     /* rounds of four candidates; the trip count is made wave-uniform */
     uint32_t rounds = (c + 3u) >> 2;
 #pragma unroll
@@ -804,19 +821,19 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* _
         const double dt2 = dt * dt;
         union { double d[2]; float f[4]; } chunk;
         if (q < DIM) {
-            const double fn = stream_load(ns.f[q] + i);
-            const double vn = stream_load(ns.v[q] + i);
-            const double adv = XSPH ? stream_load(ns.V[q] + i) : vn;
+            const double fn = n0;
+            const double vn = n1;
+            const double adv = XSPH ? n2 : vn;
             const double c1 = 0.5 * dt2 * P.omb;
             const double c2 = dt2 * P.beta;
-            const double xnew = stream_load(ns.x[q] + i) + dt * adv + c1 * fn + c2 * fd;
+            const double xnew = n3 + dt * adv + c1 * fn + c2 * fd;
             chunk.d[0] = xnew;
             chunk.d[1] = vn + hdt * (fn + fd);
             const double ex = xnew - (q == 0 ? xi0 : (q == 1 ? xi1 : xi2));
             move2 = ex * ex;
         } else if (q == 3) {
-            const float rsum = stream_load(ns.Rrho + i) + Rrho_f; /* float add, as the reference */
-            const float rho_new = (float)((double)stream_load(ns.rho + i) + hdt * (double)rsum);
+            const float rsum = (float)n0 + Rrho_f; /* float add, as the reference */
+            const float rho_new = (float)(n1 + hdt * (double)rsum);
             const float p_new = (float)(P.B * tait_pow_m1((double)rho_new / P.rho0, P.gam));
             chunk.f[0] = rho_new;
             chunk.f[1] = ri.m;
@@ -839,7 +856,7 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* _
     PHASE_MARK(3)
     /* block reductions: max(mu), max |f|^2, max move^2, sum move^2, pair count; lane 0 of each
      * quad speaks for the particle, so the butterflies start at distance 4 */
-    __shared__ double red[SPH_BLOCK / 64][5];
+    __shared__ double red[PAIR_BLOCK / 64][5];
     const bool speak = active && q == 0;
     auto quads_max = [](double v) {
 #pragma unroll
@@ -872,13 +889,13 @@ __global__ __launch_bounds__(SPH_BLOCK, 4) void k_pair(DevParams P, const Rec* _
      * memory side.  Each workgroup leaves its five partials; two small kernels fold them. */
     if (threadIdx.x == 0) {
         double a = red[0][0];
-        for (int w = 1; w < SPH_BLOCK / 64; ++w) a = fmax(a, red[w][0]);
+        for (int w = 1; w < PAIR_BLOCK / 64; ++w) a = fmax(a, red[w][0]);
         const uint32_t nb = part_n;
         part += part_base;
         part[block] = a;
         if (FUSED) {
             double b = red[0][1], c2 = red[0][2], s = red[0][3], h = red[0][4];
-            for (int w = 1; w < SPH_BLOCK / 64; ++w) {
+            for (int w = 1; w < PAIR_BLOCK / 64; ++w) {
                 b = fmax(b, red[w][1]);
                 c2 = fmax(c2, red[w][2]);
                 s += red[w][3];
