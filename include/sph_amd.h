@@ -198,6 +198,7 @@ int sph_use_rccl(sph_ctx* ctx, const void* unique_id_128);
 /* ---- the reference's case set-up, host side ----------------------------------------- */
 /* The "Simulation Definition" block (WCXSPH3D.cpp:39-48; WCXSPH.cpp:36-45; WCSPH.cpp:42-51). */
 enum { SPH_PROGRAM_WCSPH = 0, SPH_PROGRAM_WCXSPH = 1, SPH_PROGRAM_WCXSPH3D = 2 };
+enum { SPH_SIMTYPE_BOX = 0, SPH_SIMTYPE_DROPLET = 1, SPH_SIMTYPE_JET = 2 };
 typedef struct sph_case {
     int32_t program;     /* SPH_PROGRAM_* */
     int32_t npart[3];    /* xyPART */
@@ -208,6 +209,18 @@ typedef struct sph_case {
     /* Settings-file overrides of constants the reference fixes at compile time; 0 keeps the
      * reference's value (rho0 1000, Cs 50, alpha 0.025, gravity 9.81). */
     double  rho0, Cs, alpha, gravity;
+    /* Not in the reference (InitSPH only makes the box and one block): a second body of fluid
+     * on the same lattice spacing and with the block's particle mass, listed after the block.
+     * simtype 0: none; 1 (droplet): the lattice points within drop_radius of drop_centre;
+     * 2 (jet): those within drop_radius of the axis through drop_centre along the last
+     * coordinate and within drop_height/2 of it along that axis.  They start with velocity
+     * drop_v. */
+    int32_t simtype;
+    int32_t reserved_;
+    double  drop_radius;
+    double  drop_centre[3];
+    double  drop_height;
+    double  drop_v[3];
 } sph_case;
 
 /* The constants as shipped in the given reference program. */

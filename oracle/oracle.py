@@ -19,7 +19,9 @@ SEARCH_BRUTE, SEARCH_CELLS = 0, 1
 
 class Case(C.Structure):
     _fields_ = [("variant", C.c_int32), ("npart", C.c_int32 * 3), ("pstep", C.c_double),
-                ("box", C.c_double * 3), ("start", C.c_double * 3), ("dt0", C.c_double)]
+                ("box", C.c_double * 3), ("start", C.c_double * 3), ("dt0", C.c_double),
+                ("simtype", C.c_int32), ("reserved_", C.c_int32), ("drop_radius", C.c_double),
+                ("drop_centre", C.c_double * 3), ("drop_height", C.c_double), ("drop_v", C.c_double * 3)]
 
 
 class Consts(C.Structure):
@@ -80,8 +82,16 @@ def default_case(variant):
     return c
 
 
-def make_case(variant, npart, pstep, box, start, dt0=0.0002):
+def make_case(variant, npart, pstep, box, start, dt0=0.0002, drop=None):
+    """drop: None or dict(simtype=1|2, radius, centre, height, v) -- the added droplet / jet."""
     c = Case()
+    if drop:
+        c.simtype = int(drop["simtype"])
+        c.drop_radius = float(drop["radius"])
+        c.drop_height = float(drop.get("height", 0.0))
+        for d in range(3):
+            c.drop_centre[d] = float(drop["centre"][d]) if d < len(drop["centre"]) else 0.0
+            c.drop_v[d] = float(drop["v"][d]) if d < len(drop["v"]) else 0.0
     c.variant = variant
     for d in range(3):
         c.npart[d] = int(npart[d]) if d < len(npart) else 1

@@ -103,6 +103,33 @@ static uint64_t count_wall(const orc_case* c, int dim) {
     return n;
 }
 
+/* the added body (simtype 1, 2): visit(x) for each lattice point, i slowest */
+template <typename Visit>
+static void visit_drop(const orc_case* c, int dim, Visit visit) {
+    if (c->simtype != 1 && c->simtype != 2) return;
+    const int m = (int)floor(c->drop_radius / c->pstep);
+    const int mh = c->simtype == 2 ? (int)floor(0.5 * c->drop_height / c->pstep) : m;
+    const int last = dim - 1;
+    int lim[3] = {m, m, m};
+    lim[last] = mh;
+    if (dim == 2) lim[2] = 0;
+    for (int i = -lim[0]; i <= lim[0]; ++i)
+        for (int j = -lim[1]; j <= lim[1]; ++j)
+            for (int kk = -lim[2]; kk <= lim[2]; ++kk) {
+                const int idx[3] = {i, j, kk};
+                double r2 = 0.0;
+                for (int d = 0; d < dim; ++d) {
+                    if (c->simtype == 2 && d == last) continue;
+                    const double dd = idx[d] * c->pstep;
+                    r2 += dd * dd;
+                }
+                if (r2 > c->drop_radius * c->drop_radius) continue;
+                double x[3] = {0, 0, 0};
+                for (int d = 0; d < dim; ++d) x[d] = c->drop_centre[d] + idx[d] * c->pstep;
+                visit(x);
+            }
+}
+
 int orc_derive(const orc_case* c, orc_consts* k) {
     memset(k, 0, sizeof(*k));
     if (c->variant < ORC_WCSPH || c->variant > ORC_WCXSPH3D) return 1;
@@ -125,6 +152,11 @@ int orc_derive(const orc_case* c, orc_consts* k) {
     if (c->variant == ORC_WCXSPH3D) k->boundmass = 1.0 * k->rho0 * (vol / (1.0 * k->sim_pts));
     else if (c->variant == ORC_WCXSPH) k->boundmass = 0.9 * k->rho0 * (vol / (1.0 * k->sim_pts));
     else k->boundmass = k->simmass;
+    {   /* the added body shares the block's spacing and mass; it only adds points */
+        uint64_t extra = 0;
+        visit_drop(c, dim, [&](const double*) { ++extra; });
+        k->sim_pts += extra;
+    }
     k->Cs = 50;
     k->gam = 7.0;
     k->B = k->rho0 * pow(k->Cs, 2) / k->gam; /* WCXSPH3D.cpp:56 */
@@ -233,6 +265,11 @@ static void init_sph(const orc_case* c, const orc_consts* k, State& ps) {
                     ps.push_back(make_particle(x, 3, rho, Rrho, sm));
                 }
     }
+    visit_drop(c, dim, [&](const double* x) {
+        Particle P = make_particle(x, dim, rho, Rrho, sm);
+        for (int d = 0; d < dim; ++d) P.v[d] = c->drop_v[d];
+        ps.push_back(P);
+    });
 }
 
 /* ------------------------------------------------------------------------------------------ */

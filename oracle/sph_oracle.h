@@ -38,6 +38,17 @@ typedef struct orc_case {
     double  box[3];       /* Box */
     double  start[3];     /* Start */
     double  dt0;          /* initial dt (reference: 0.0002) */
+    /* Not in the reference (its InitSPH only makes the box and one block): a second body of
+     * fluid on the same lattice spacing, listed after the block.  simtype 0: none; 1: the
+     * lattice points within drop_radius of drop_centre (droplet); 2: those within drop_radius
+     * of the vertical axis through drop_centre and within drop_height/2 of it along the last
+     * axis (jet).  All of them start with velocity drop_v. */
+    int32_t simtype;
+    int32_t reserved_;
+    double  drop_radius;
+    double  drop_centre[3];
+    double  drop_height;
+    double  drop_v[3];
 } orc_case;
 
 /* Derived constants (WCXSPH3D.cpp:50-79,97 and the parallel 2-D lines). */

@@ -61,7 +61,9 @@ class Scalars(C.Structure):
 class Case(C.Structure):
     _fields_ = [("program", C.c_int32), ("npart", C.c_int32 * 3), ("pstep", C.c_double),
                 ("box", C.c_double * 3), ("start", C.c_double * 3), ("dt0", C.c_double),
-                ("rho0", C.c_double), ("Cs", C.c_double), ("alpha", C.c_double), ("gravity", C.c_double)]
+                ("rho0", C.c_double), ("Cs", C.c_double), ("alpha", C.c_double), ("gravity", C.c_double),
+                ("simtype", C.c_int32), ("reserved_", C.c_int32), ("drop_radius", C.c_double),
+                ("drop_centre", C.c_double * 3), ("drop_height", C.c_double), ("drop_v", C.c_double * 3)]
 
 
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -144,8 +146,20 @@ def default_case(program):
     return c
 
 
-def make_case(program, npart, pstep, box, start, dt0=0.0002):
+SIMTYPE_BOX, SIMTYPE_DROPLET, SIMTYPE_JET = 0, 1, 2
+
+
+def make_case(program, npart, pstep, box, start, dt0=0.0002, drop=None):
+    """drop: None or dict(simtype=1|2, radius, centre, height, v) -- a droplet / jet next to the
+    reference's block (no counterpart in the reference)."""
     c = Case()
+    if drop:
+        c.simtype = int(drop["simtype"])
+        c.drop_radius = float(drop["radius"])
+        c.drop_height = float(drop.get("height", 0.0))
+        for d in range(3):
+            c.drop_centre[d] = float(drop["centre"][d]) if d < len(drop["centre"]) else 0.0
+            c.drop_v[d] = float(drop["v"][d]) if d < len(drop["v"]) else 0.0
     c.program = program
     for d in range(3):
         c.npart[d] = int(npart[d]) if d < len(npart) else 1

@@ -37,6 +37,36 @@ WallGrid wall_grid(const sph_case* c) {
 
 /* Visits every particle of InitSPH in the reference's order: walls first, then the fluid
  * block.  emit(x, is_wall). */
+/* the added droplet / jet: lattice points around drop_centre, first index slowest */
+template <typename Emit>
+void visit_added_body(const sph_case* c, Emit emit) {
+    if (c->simtype != SPH_SIMTYPE_DROPLET && c->simtype != SPH_SIMTYPE_JET) return;
+    const int dim = case_dim(c), last = dim - 1;
+    const int m = (int)floor(c->drop_radius / c->pstep);
+    int lim[3] = {m, m, m};
+    if (c->simtype == SPH_SIMTYPE_JET) lim[last] = (int)floor(0.5 * c->drop_height / c->pstep);
+    if (dim == 2) lim[2] = 0;
+    for (int i = -lim[0]; i <= lim[0]; ++i)
+        for (int j = -lim[1]; j <= lim[1]; ++j)
+            for (int k = -lim[2]; k <= lim[2]; ++k) {
+                const int idx[3] = {i, j, k};
+                double r2 = 0.0;
+                for (int d = 0; d < dim; ++d) {
+                    if (c->simtype == SPH_SIMTYPE_JET && d == last) continue;
+                    const double dd = idx[d] * c->pstep;
+                    r2 += dd * dd;
+                }
+                if (r2 > c->drop_radius * c->drop_radius) continue;
+                double x[3] = {0, 0, 0};
+                for (int d = 0; d < dim; ++d) x[d] = c->drop_centre[d] + idx[d] * c->pstep;
+                emit(x, false);
+            }
+}
+
+/* emit(x, is_wall, in_added_body) */
+template <typename Emit>
+void visit_all(const sph_case* c, Emit emit);
+
 template <typename Emit>
 void visit_particles(const sph_case* c, Emit emit) {
     const WallGrid w = wall_grid(c);
@@ -85,6 +115,12 @@ void visit_particles(const sph_case* c, Emit emit) {
                 x[2] = c->start[2] + k * c->pstep;
                 emit(x, false);
             }
+}
+
+template <typename Emit>
+void visit_all(const sph_case* c, Emit emit) {
+    visit_particles(c, [&](const double* x, bool wall) { emit(x, wall, false); });
+    visit_added_body(c, [&](const double* x, bool) { emit(x, false, true); });
 }
 
 uint64_t wall_count(const sph_case* c) {
@@ -148,7 +184,9 @@ int sph_case_params(const sph_case* c, sph_params* p, double* simmass_out, doubl
     p->dim = dim;
     p->variant = c->program == SPH_PROGRAM_WCSPH ? SPH_VARIANT_WCSPH : SPH_VARIANT_WCXSPH;
     p->bound_parts = wall_count(c);
-    p->npts = p->bound_parts + simpts;
+    uint64_t added = 0;
+    visit_added_body(c, [&](const double*, bool) { ++added; });
+    p->npts = p->bound_parts + simpts + added;
     /* H (WCXSPH3D.cpp:59 keeps the square root and multiplies by 3; WCXSPH.cpp:56; WCSPH.cpp:61) */
     const double h2d = sqrt((3 / M_PI) * (simmass / rho0));
     p->H = dim == 3 ? 3 * h2d : h2d;
@@ -190,10 +228,10 @@ int sph_case_init(const sph_case* c, const sph_fields* dst) {
     const float rho = (float)p.rho0;
     const float wall_m = (float)boundmass, fluid_m = (float)simmass;
     uint64_t i = 0;
-    visit_particles(c, [&](const double* x, bool wall) {
+    visit_all(c, [&](const double* x, bool wall, bool added) {
         for (int d = 0; d < dim; ++d) {
             if (dst->x[d]) dst->x[d][i] = x[d];
-            if (dst->v[d]) dst->v[d][i] = 0.0;
+            if (dst->v[d]) dst->v[d][i] = added ? c->drop_v[d] : 0.0;
             if (dst->V[d]) dst->V[d][i] = 0.0;
             if (dst->f[d]) dst->f[d][i] = 0.0;
         }
@@ -218,13 +256,13 @@ int sph_case_init_range(const sph_case* c, double xlo, double xhi, const sph_fie
     const float rho = (float)p.rho0;
     const float wall_m = (float)boundmass, fluid_m = (float)simmass;
     uint64_t i = 0, g = 0;
-    visit_particles(c, [&](const double* x, bool wall) {
+    visit_all(c, [&](const double* x, bool wall, bool added) {
         const uint64_t gi = g++;
         if (!(x[0] >= xlo && x[0] < xhi)) return;
         if (dst) {
             for (int d = 0; d < dim; ++d) {
                 if (dst->x[d]) dst->x[d][i] = x[d];
-                if (dst->v[d]) dst->v[d][i] = 0.0;
+                if (dst->v[d]) dst->v[d][i] = added ? c->drop_v[d] : 0.0;
                 if (dst->V[d]) dst->V[d][i] = 0.0;
                 if (dst->f[d]) dst->f[d][i] = 0.0;
             }
@@ -247,7 +285,7 @@ int sph_case_histogram_x(const sph_case* c, int32_t nbins, uint64_t* fluid_count
     if (rc != SPH_OK) return rc;
     for (int b = 0; b < nbins; ++b) fluid_counts[b] = wall_counts[b] = 0;
     const double scale = nbins / c->box[0];
-    visit_particles(c, [&](const double* x, bool wall) {
+    visit_all(c, [&](const double* x, bool wall, bool) {
         double b = floor(x[0] * scale);
         if (!(b >= 0)) b = 0;
         if (b > nbins - 1) b = nbins - 1;

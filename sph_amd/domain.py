@@ -13,6 +13,7 @@ Two transports move the bytes:
 import ctypes as C
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -194,7 +195,7 @@ def bench_main(args, world, rank, local_rank, fluid):
         if int(failed[0]):
             # no communicator (e.g. ranks sharing a GPU): every rank moves to the staged transport
             if why and rank == 0:
-                print("RCCL transport unavailable (%s); halo bytes staged through the host" % why, flush=True)
+                print("RCCL transport unavailable (%s); halo bytes staged through the host" % why, file=sys.stderr, flush=True)
             transport = "host"
     if transport == "rccl":
         pass

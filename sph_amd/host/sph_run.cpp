@@ -20,7 +20,10 @@
  *   Bulk_mod X               no counterpart: the reference derives the Tait modulus from the
  *                            speed of sound (B = rho0*Cs^2/gam, WCXSPH3D.cpp:54-56); accepted
  *                            and ignored with a notice
- *   simtype Box              the only initialiser the reference has
+ *   simtype Box|Droplet|Jet  Box is the only initialiser the reference has; Droplet / Jet add a
+ *                            sphere / vertical cylinder of fluid on the block's lattice spacing:
+ *                            drop_radius R, drop_centre X Y [Z], drop_height L (Jet),
+ *                            drop_velocity VX VY [VZ]
  * Extensions of this driver:
  *   program WCSPH|WCXSPH|WCXSPH3D   which reference program to run  (default WCXSPH)
  *   npart NX NY [NZ], box BX BY [BZ], start SX SY [SZ], cs X
@@ -50,6 +53,8 @@ struct Settings {
     bool have_npart = false, have_box = false, have_start = false;
     double dt = 0, psize = 0, rho_ref = 0, viscosity = 0, gravity = 0, cs = 0;
     double npart[3] = {0, 0, 0}, box[3] = {0, 0, 0}, start[3] = {0, 0, 0};
+    int simtype = SPH_SIMTYPE_BOX;
+    double drop_radius = 0, drop_height = 0, drop_centre[3] = {0, 0, 0}, drop_v[3] = {0, 0, 0};
 };
 
 bool read_settings(const char* path, Settings& s) {
@@ -73,7 +78,17 @@ bool read_settings(const char* path, Settings& s) {
         else if (key == "gravity") ls >> s.gravity;
         else if (key == "cs") ls >> s.cs;
         else if (key == "Bulk_mod") std::cout << "Note: Bulk_mod has no counterpart (B follows from the speed of sound); ignored." << std::endl;
-        else if (key == "simtype") { std::string v; ls >> v; if (v != "Box") { std::cerr << "Unknown simtype " << v << std::endl; return false; } }
+        else if (key == "simtype") {
+            std::string v; ls >> v;
+            if (v == "Box") s.simtype = SPH_SIMTYPE_BOX;
+            else if (v == "Droplet") s.simtype = SPH_SIMTYPE_DROPLET;
+            else if (v == "Jet") s.simtype = SPH_SIMTYPE_JET;
+            else { std::cerr << "Unknown simtype " << v << std::endl; return false; }
+        }
+        else if (key == "drop_radius") ls >> s.drop_radius;
+        else if (key == "drop_height") ls >> s.drop_height;
+        else if (key == "drop_centre") { for (int d = 0; d < 3 && (ls >> s.drop_centre[d]); ++d) {} }
+        else if (key == "drop_velocity") { for (int d = 0; d < 3 && (ls >> s.drop_v[d]); ++d) {} }
         else if (key == "program") {
             std::string v; ls >> v;
             if (v == "WCSPH") s.program = SPH_PROGRAM_WCSPH;
@@ -202,6 +217,10 @@ int main(int argc, char* argv[]) {
             if (st.have_box && st.box[d] > 0) cs.box[d] = st.box[d];
             if (st.have_start) cs.start[d] = st.start[d];
         }
+        cs.simtype = st.simtype;
+        cs.drop_radius = st.drop_radius;
+        cs.drop_height = st.drop_height;
+        for (int d = 0; d < 3; ++d) { cs.drop_centre[d] = st.drop_centre[d]; cs.drop_v[d] = st.drop_v[d]; }
     }
     sph_params prm;
     double simmass = 0, boundmass = 0;

@@ -30,7 +30,8 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     spec = json.loads(args.spec)
     if "npart" in spec:
-        case = capi.make_case(spec["program"], spec["npart"], spec["pstep"], spec["box"], spec["start"])
+        case = capi.make_case(spec["program"], spec["npart"], spec["pstep"], spec["box"], spec["start"],
+                              drop=spec.get("drop"))
     else:
         case = capi.default_case(spec["program"])
     over = {"skin_frac": args.skin} if args.skin > 0 else {}

@@ -36,7 +36,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(capi.Params) == 8 + 16 + 8 * 10 + 8 + 8 + 8 * 4 + 8 + 8 + 8 * 4 + 8 + 8
     assert C.sizeof(capi.Fields) == 8 * 16
     assert C.sizeof(capi.Scalars) == 8 + 8 + 8 * 4 + 8 * 3
-    assert C.sizeof(capi.Case) == 16 + 8 + 24 + 24 + 8 + 32
+    assert C.sizeof(capi.Case) == 16 + 8 + 24 + 24 + 8 + 32 + 8 + 8 + 24 + 8 + 24
 
 
 @pytest.mark.parametrize("program", [0, 1, 2])
@@ -64,6 +64,25 @@ def test_scaled_case_setup_matches_oracle():
         ost = O.Oracle(oc).get_state(O.STATE_N)
         assert np.array_equal(st["x"].T, ost["x"]), name
         assert np.array_equal(st["m"], ost["m"]), name
+
+
+def test_droplet_and_jet_setup_matches_oracle():
+    for name, spec in util.drop_cases().items():
+        oc, pc = util.both_cases(spec)
+        p, st = capi.case_init(pc)
+        orc = O.Oracle(oc)
+        ost = orc.get_state(O.STATE_N)
+        assert int(p.npts) == orc.npts and int(p.bound_parts) == orc.bound_parts, name
+        assert np.array_equal(st["x"].T, ost["x"]) and np.array_equal(st["v"].T, ost["v"]), name
+        assert np.array_equal(st["m"], ost["m"]), name
+        plain = dict(spec)
+        del plain["drop"]
+        p0, _, _ = capi.case_params(util.both_cases(plain)[1])
+        added = int(p.npts) - int(p0.npts)
+        assert added > 20, name
+        assert (p.H, p.mass) == (p0.H, p0.mass)  # the added body does not change the constants
+        moving = np.any(st["v"] != 0.0, axis=0)
+        assert moving.sum() == added and not moving[: int(p0.npts)].any(), name
 
 
 def test_bad_case_is_rejected():

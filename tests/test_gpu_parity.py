@@ -361,3 +361,20 @@ def test_working_lists_too_tight_fall_back_to_the_candidates():
     assert sc["step_redos"] > before > 0
     assert_state_close(sim.download(capi.STATE_N), orc.get_state(O.STATE_N), "tight working lists")
     sim.close()
+
+
+# ---- droplet / jet bodies (initialisers beyond the reference's box block) ------------------------
+
+@pytest.mark.parametrize("name", list(util.drop_cases()))
+def test_droplet_and_jet_steps(name):
+    spec = util.drop_cases()[name]
+    orc, sim = start(spec)
+    go, gc = sim.neighbours(capi.STATE_N)
+    oo, occ = orc.neighbours(O.STATE_N)
+    assert np.array_equal(go, oo) and np.array_equal(gc, occ)
+    orc.step(20)
+    sc = sim.step(20)
+    assert_state_close(sim.download(capi.STATE_N), orc.get_state(O.STATE_N), name)
+    assert_scalars_close(sc, orc.scalars(), name)
+    assert sc["maxmu"] > 0  # the body has reached the pool or the wall: viscosity is at work
+    sim.close()

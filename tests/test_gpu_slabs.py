@@ -142,3 +142,15 @@ def test_without_migration_the_answer_is_the_same(tmp_path):
     orc, f0, nb = oracle_run(spec, 8, vx=0.8)
     check(res, orc, f0, nb, "drifting block on 2 slabs, owners fixed")
     assert res["moved"][:, 1].sum() == 0
+
+
+@pytest.mark.parametrize("name,nranks", [("droplet3d", 2), ("jet3d", 3), ("droplet2d", 2)])
+def test_droplet_and_jet_on_slabs(name, nranks, tmp_path):
+    # non-uniform density (the planes follow the particle count, not the box) and bodies that
+    # cross the planes: halo sizes differ per side and particles change owner on the way
+    spec = util.drop_cases()[name]
+    steps = 20
+    res = run_slabs(spec, nranks, tmp_path, steps=steps, skin=0.01)
+    orc, f0, nb = oracle_run(spec, steps)
+    check(res, orc, f0, nb, "%s on %d slabs" % (name, nranks))
+    assert res["moved"][:, 0].sum() == orc.npts

@@ -28,7 +28,21 @@ def both_cases(spec):
     if "npart" not in spec:
         return O.default_case(prog), capi.default_case(prog)
     args = (spec["npart"], spec["pstep"], spec["box"], spec["start"], spec.get("dt0", 0.0002))
-    return O.make_case(prog, *args), capi.make_case(prog, *args)
+    drop = spec.get("drop")
+    return O.make_case(prog, *args, drop=drop), capi.make_case(prog, *args, drop=drop)
+
+
+def drop_cases():
+    """Bodies the reference's InitSPH cannot make: a droplet falling into a shallow pool and a
+    jet crossing the box (non-uniform density; with an x-velocity they also cross slab planes)."""
+    return {
+        "droplet3d": dict(program=2, npart=(16, 10, 3), pstep=0.1, box=(2.0, 1.4, 2.0), start=(0.1, 0.1, 0.1),
+                          drop=dict(simtype=1, radius=0.31, centre=(0.95, 0.65, 1.0), v=(0.6, 0.0, -2.0))),
+        "jet3d": dict(program=2, npart=(16, 10, 2), pstep=0.1, box=(2.0, 1.4, 2.0), start=(0.1, 0.1, 0.1),
+                      drop=dict(simtype=2, radius=0.21, centre=(0.75, 0.65, 1.1), height=1.0, v=(1.5, 0.0, -1.0))),
+        "droplet2d": dict(program=1, npart=(60, 8), pstep=0.05, box=(4.0, 3.0), start=(0.06, 0.06),
+                          drop=dict(simtype=1, radius=0.26, centre=(1.9, 1.5), v=(0.8, -2.0))),
+    }
 
 
 def to_particle_major(st):
