@@ -525,7 +525,14 @@ __device__ __forceinline__ double fast_sqrt(double x) {
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef double f64x2_t __attribute__((ext_vector_type(2)));
 template <typename T>
-__device__ __forceinline__ T stream_load(const T* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ T stream_load(const T* p) {
+#ifdef SPH_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p; /* measured: the hint on loads buys no time and costs 30 % more fetched bytes
+                  (a row's second half is fetched again) */
+#endif
+}
 template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
 

@@ -26,6 +26,30 @@ __global__ void k_stream8(const double* __restrict__ a, size_t n, uint32_t* sink
     for (; i < n; i += (size_t)gridDim.x * blockDim.x) acc += a[i];
     if (acc == 1.2345) *sink = 1;
 }
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// the same streams with the non-temporal hint the pair kernel puts on its streamed loads
+__global__ void k_stream16_nt(const u32x4_t* __restrict__ a, size_t n, uint32_t* sink) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        u32x4_t v = __builtin_nontemporal_load(a + i);
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+__global__ void k_stream8_nt(const double* __restrict__ a, size_t n, uint32_t* sink) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double acc = 0;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) acc += __builtin_nontemporal_load(a + i);
+    if (acc == 1.2345) *sink = 1;
+}
+__global__ void k_store16_nt(u32x4_t* __restrict__ a, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        u32x4_t v = {(uint32_t)i, 1u, 2u, 3u};
+        __builtin_nontemporal_store(v, a + i);
+    }
+}
 __global__ void k_quad_gather(const uint4* __restrict__ rec, const uint32_t* __restrict__ perm, size_t nrec, uint32_t* sink) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t q = threadIdx.x & 3;
@@ -73,6 +97,9 @@ int main() {
     hipLaunchKernelGGL(k_quad_gather, g, t, 0, 0, (const uint4*)a, perm, nrec, sink); // 2 GiB + perm 128 MiB
     hipLaunchKernelGGL(k_store16, g, t, 0, 0, (uint4*)b, bytes / 16);                // 2 GiB written
     hipLaunchKernelGGL(k_store8, g, t, 0, 0, (double*)a, bytes / 8);                 // 2 GiB written
+    hipLaunchKernelGGL(k_stream16_nt, g, t, 0, 0, (const u32x4_t*)b, bytes / 16, sink); // 2 GiB read
+    hipLaunchKernelGGL(k_stream8_nt, g, t, 0, 0, (const double*)a, bytes / 8, sink);    // 2 GiB read
+    hipLaunchKernelGGL(k_store16_nt, g, t, 0, 0, (u32x4_t*)b, bytes / 16);              // 2 GiB written
     CK(hipDeviceSynchronize());
     printf("expected KiB: stream16/stream8 read %zu; quad_gather read %zu (+%zu perm); stores %zu\n", bytes >> 10, bytes >> 10,
            (nrec * 4) >> 10, bytes >> 10);
