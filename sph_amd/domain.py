@@ -180,7 +180,23 @@ def bench_main(args, world, rank, local_rank, fluid):
     nx, ny, nz = fluid
     case = B.dam_break_3d(nx * world, ny, nz)
     t_setup = time.perf_counter()
-    sim = SlabSim.from_case(case, rank, world, device=local_rank)
+
+    def all_ok(err):
+        """A rank that failed must not leave the others waiting in a collective: agree first."""
+        flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if err:
+            print("rank %d: %s" % (rank, err), file=sys.stderr, flush=True)
+        if int(flag[0]):
+            dist.destroy_process_group()
+            raise SystemExit(1)
+
+    sim, err = None, None
+    try:
+        sim = SlabSim.from_case(case, rank, world, device=local_rank)
+    except Exception as e:  # reported below, on every rank
+        err = repr(e)
+    all_ok(err)
     transport = os.environ.get("SPH_TRANSPORT", "rccl")
     if transport == "rccl":
         ident = [capi.rccl_unique_id() if rank == 0 else None]
@@ -210,6 +226,7 @@ def bench_main(args, world, rank, local_rank, fluid):
 
     for _ in range(args.warmup):
         sim.step(1)
+    all_ok(None)
     sim.profile_enable(True)
     sim.profile_read()
     torch.cuda.synchronize()
