@@ -543,6 +543,9 @@ __device__ unsigned long long g_phase[8];
 #define PHASE_MARK(k)
 #endif
 
+#ifndef PAIR_WAVES
+#define PAIR_WAVES 4 /* resident waves per SIMD the register budget is set for */
+#endif
 #ifndef PAIR_BLOCK
 #define PAIR_BLOCK 256 /* threads per workgroup of the pair kernel */
 #endif
@@ -574,7 +577,7 @@ __device__ unsigned long long g_phase[8];
  *  sweep of a step, which tests every candidate anyway, writes out those within a tighter
  *  radius (same order); the other sweeps walk that shorter list. */
 template <int DIM, bool XSPH, bool FUSED, bool FILTER, bool WIDE>
-__global__ __launch_bounds__(PAIR_BLOCK, 4) void k_pair(DevParams P, const Rec* __restrict__ rin,
+__global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, const Rec* __restrict__ rin,
                                                     const uint32_t* __restrict__ nbr, uint32_t stride,
                                                     const uint32_t* __restrict__ cnt, OutState out, int store_out,
                                                     int zero_wall, NState ns, const uint32_t* __restrict__ id,
