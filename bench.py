@@ -55,7 +55,7 @@ def measured_traffic(fluid, n):
     return reads + t["write_size_kib"] * 1024.0
 
 
-def cpu_baseline(sample=(64, 48, 32), steps=1):
+def cpu_baseline(sample=(64, 48, 32), steps=4):
     """The oracle (a port: the reference itself needs Eigen+nanoflann) on one host core, on
     a reduced block of the same case."""
     from oracle import oracle as O
