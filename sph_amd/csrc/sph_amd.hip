@@ -798,7 +798,6 @@ int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out
     if (count == 0) return SPH_OK;
     NState ns = n_state(c);
     dim3 g(pairblocks(count)), b(PAIR_BLOCK);
-    static const int dbg = getenv("SPH_DBG") ? atoi(getenv("SPH_DBG")) : 0; /* timing experiments only */
     /* FILTER: walk the candidate lists and write the step's working lists */
     const uint32_t* walk = FILTER ? c->nbr : c->use_nbr;
     const uint32_t* walk_cnt = FILTER ? c->cnt : c->use_cnt;
@@ -806,7 +805,7 @@ int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out
     const bool wide = (uint64_t)c->cap * sizeof(Rec) >= (1ull << 32);
 #define LP(D, X, W)                                                                                                   \
     hipLaunchKernelGGL((k_pair<D, X, FUSED, FILTER, W>), g, b, 0, c->stream, c->dp, rin, walk, c->cap_k, walk_cnt, o, \
-                       store_out, zero_wall, ns, wall_ids(c), rout, c->pp, c->S, c->part, dbg, first, count,          \
+                       store_out, zero_wall, ns, wall_ids(c), rout, c->pp, c->S, c->part, first, count,               \
                        part_base, part_n, c->nbr_in, c->cnt_in, c->r_in2)
     if (c->dim == 3) { if (wide) LP(3, true, true); else LP(3, true, false); }
     else if (c->xsph) { if (wide) LP(2, true, true); else LP(2, true, false); }

@@ -582,7 +582,7 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
                                                     const uint32_t* __restrict__ cnt, OutState out, int store_out,
                                                     int zero_wall, NState ns, const uint32_t* __restrict__ id,
                                                     Rec* __restrict__ rout, float* __restrict__ pout,
-                                                    DevScalars* __restrict__ S, double* __restrict__ part, int dbg,
+                                                    DevScalars* __restrict__ S, double* __restrict__ part,
                                                     uint32_t first, uint32_t count, uint32_t part_base,
                                                     uint32_t part_n, uint32_t* __restrict__ nbr_out,
                                                     uint32_t* __restrict__ cnt_out, double r_in2) {
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
         const Rec rj = exchange();                             \
         const uint32_t jcur = jnext;                           \
         if (t + 1 < rounds) LOAD_FROM(NEXTVEC, NEXTR, t + 1)   \
-        if (!(dbg & 2)) pair_term(t, rj, jcur);                \
+        pair_term(t, rj, jcur);                                \
     }
 
     PHASE_MARK(1)
