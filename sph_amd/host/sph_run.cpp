@@ -29,6 +29,11 @@
  *   npart NX NY [NZ], box BX BY [BZ], start SX SY [SZ], cs X
  *   reinit 0|1               per-frame DensityReinit                (default 1)
  *   device N                 HIP device ordinal
+ *   frame_stride K           write every K-th frame to the .plt     (default 1: all, as the reference)
+ *   threads N                host threads that format a frame       (default: the machine's, at most 16)
+ * The rows of a frame are formatted by several threads into memory and written in order, and the
+ * file is written while the GPU computes the next frame; the bytes are the same as from the
+ * reference's single `f1 << ... << std::endl` loop.
  */
 #include "../../include/sph_amd.h"
 
@@ -38,8 +43,10 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <cstdio>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -50,6 +57,7 @@ struct Settings {
     int nframes = 2000, npframe = 10;
     int program = SPH_PROGRAM_WCXSPH;
     int reinit = 1, device = -1;
+    int frame_stride = 1, threads = 0;
     bool have_npart = false, have_box = false, have_start = false;
     double dt = 0, psize = 0, rho_ref = 0, viscosity = 0, gravity = 0, cs = 0;
     double npart[3] = {0, 0, 0}, box[3] = {0, 0, 0}, start[3] = {0, 0, 0};
@@ -101,6 +109,8 @@ bool read_settings(const char* path, Settings& s) {
         else if (key == "start") { s.have_start = true; for (int d = 0; d < 3 && (ls >> s.start[d]); ++d) {} }
         else if (key == "reinit") ls >> s.reinit;
         else if (key == "device") ls >> s.device;
+        else if (key == "frame_stride") { ls >> s.frame_stride; if (s.frame_stride < 1) s.frame_stride = 1; }
+        else if (key == "threads") ls >> s.threads;
         else std::cout << "Note: unknown settings key '" << key << "' ignored." << std::endl;
     }
     return true;
@@ -154,37 +164,69 @@ void write_settings(const std::string& name, int nframes, int npframe, double dt
 }
 
 /* write_frame_data (WCXSPH3D.cpp:408-437; WCSPH.cpp:378-410 adds DATAPACKING=POINT and prints
- * the components in its NaN report) */
-void write_frame(HostState& s, std::ofstream& fp, float t, uint64_t bound_parts, int program) {
-    auto row = [&](std::ostream& o, size_t i) {
-        for (int d = 0; d < s.dim; ++d) o << s.x[d][i] << " ";
-        o << s.norm(s.v, i) << " ";
-        o << s.norm(s.f, i) << " ";
-        o << s.rho[i] << " " << s.p[i] << std::endl;
-    };
+ * the components in its NaN report).  One row: x y [z] |v| |f| rho p, fixed, three decimals --
+ * printf's "%.3f" produces the characters `std::fixed << std::setprecision(3)` does. */
+void format_rows(const HostState& s, size_t lo, size_t hi, std::string& out) {
+    char buf[256];
+    out.clear();
+    out.reserve((hi - lo) * 56);
+    for (size_t i = lo; i < hi; ++i) {
+        int n = 0;
+        for (int d = 0; d < s.dim; ++d) n += snprintf(buf + n, sizeof buf - n, "%.3f ", s.x[d][i]);
+        n += snprintf(buf + n, sizeof buf - n, "%.3f %.3f %.3f %.3f\n", s.norm(s.v, i), s.norm(s.f, i), (double)s.rho[i],
+                      (double)s.p[i]);
+        out.append(buf, (size_t)n);
+    }
+}
+
+/* first fluid particle with a NaN in x, v or f, or n if there is none */
+size_t first_broken(const HostState& s, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i)
+        for (int d = 0; d < s.dim; ++d)
+            if (s.x[d][i] != s.x[d][i] || s.v[d][i] != s.v[d][i] || s.f[d][i] != s.f[d][i]) return i;
+    return s.n;
+}
+
+void write_frame(const HostState& s, std::ofstream& fp, float t, uint64_t bound_parts, int program, int nthreads) {
+    /* the reference stops at the first broken fluid row, after writing the rows before it */
+    const size_t bad = first_broken(s, (size_t)bound_parts, s.n);
+    const size_t stop = bad < s.n ? bad : s.n;
+    /* chunks [0, bound) and [bound, stop), each cut into pieces formatted in parallel */
+    std::vector<std::pair<size_t, size_t> > pieces;
+    const size_t per = std::max<size_t>(65536, (stop + nthreads - 1) / std::max(nthreads, 1));
+    size_t wall_pieces = 0;
+    for (size_t lo = 0; lo < bound_parts; lo += per) { pieces.push_back(std::make_pair(lo, std::min<size_t>(lo + per, bound_parts))); ++wall_pieces; }
+    for (size_t lo = bound_parts; lo < stop; lo += per) pieces.push_back(std::make_pair(lo, std::min(lo + per, stop)));
+    std::vector<std::string> text(pieces.size());
+    std::vector<std::thread> pool;
+    const int workers = std::max(1, std::min<int>(nthreads, (int)pieces.size()));
+    for (int w = 0; w < workers; ++w)
+        pool.emplace_back([&, w]() {
+            for (size_t k = (size_t)w; k < pieces.size(); k += (size_t)workers) format_rows(s, pieces[k].first, pieces[k].second, text[k]);
+        });
+    for (auto& th : pool) th.join();
     fp << "ZONE t=\"Boundary Data\", STRANDID=1, SOLUTIONTIME=" << t << std::endl;
-    for (size_t i = 0; i < bound_parts; ++i) row(fp, i);
+    for (size_t k = 0; k < wall_pieces; ++k) fp.write(text[k].data(), (std::streamsize)text[k].size());
     fp << "ZONE t=\"Particle Data\", STRANDID=2, SOLUTIONTIME=" << t;
     if (program == SPH_PROGRAM_WCSPH) fp << ", DATAPACKING=POINT";
     fp << std::endl;
-    for (size_t i = bound_parts; i < s.n; ++i) {
-        bool bad = false;
-        for (int d = 0; d < s.dim; ++d) bad = bad || s.x[d][i] != s.x[d][i] || s.v[d][i] != s.v[d][i] || s.f[d][i] != s.f[d][i];
-        if (bad) {
-            std::cerr << std::endl << "Simulation is broken. A value is nan." << std::endl;
-            std::cerr << "Broken line..." << std::endl;
-            if (program == SPH_PROGRAM_WCSPH) {
-                for (int d = 0; d < s.dim; ++d) std::cerr << s.x[d][i] << " ";
-                for (int d = 0; d < s.dim; ++d) std::cerr << s.v[d][i] << " ";
-                for (int d = 0; d < s.dim; ++d) std::cerr << s.f[d][i] << " ";
-                std::cerr << s.rho[i] << " " << s.p[i] << std::endl;
-            } else {
-                row(std::cerr, i);
-            }
-            fp.close();
-            exit(-1);
+    for (size_t k = wall_pieces; k < pieces.size(); ++k) fp.write(text[k].data(), (std::streamsize)text[k].size());
+    if (bad < s.n) {
+        const size_t i = bad;
+        std::cerr << std::endl << "Simulation is broken. A value is nan." << std::endl;
+        std::cerr << "Broken line..." << std::endl;
+        std::cerr << std::fixed << std::setprecision(3);
+        if (program == SPH_PROGRAM_WCSPH) {
+            for (int d = 0; d < s.dim; ++d) std::cerr << s.x[d][i] << " ";
+            for (int d = 0; d < s.dim; ++d) std::cerr << s.v[d][i] << " ";
+            for (int d = 0; d < s.dim; ++d) std::cerr << s.f[d][i] << " ";
+            std::cerr << s.rho[i] << " " << s.p[i] << std::endl;
+        } else {
+            for (int d = 0; d < s.dim; ++d) std::cerr << s.x[d][i] << " ";
+            std::cerr << s.norm(s.v, i) << " " << s.norm(s.f, i) << " " << s.rho[i] << " " << s.p[i] << std::endl;
         }
-        row(fp, i);
+        fp.close();
+        exit(-1);
     }
 }
 
@@ -233,9 +275,11 @@ int main(int argc, char* argv[]) {
 
     /* InitSPH (WCXSPH3D.cpp:306-379) */
     std::cout << "Initialising simulation with " << simpts << " particles" << std::endl;
-    HostState hs;
+    HostState hs, hs_alt; /* two sets: one is written to the file while the other is filled */
     hs.resize(prm.dim, (size_t)prm.npts);
+    hs_alt.resize(prm.dim, (size_t)prm.npts);
     sph_fields h = hs.fields();
+    int nthreads = st.threads > 0 ? st.threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (sph_case_init(&cs, &h) != SPH_OK) exit(-1);
     std::cout << "Total Particles: " << prm.npts << std::endl;
 
@@ -256,18 +300,30 @@ int main(int argc, char* argv[]) {
         std::cout << "Starting simulation..." << std::endl;
         f1 << (prm.dim == 3 ? "VARIABLES = x, y, z, V, F, rho, P" : "VARIABLES = x, y, V, F, rho, P") << std::endl;
         if (sph_download(ctx, SPH_STATE_N, &h) != SPH_OK) die(ctx, "sph_download");
-        write_frame(hs, f1, 0.f, prm.bound_parts, st.program);
+        write_frame(hs, f1, 0.f, prm.bound_parts, st.program, nthreads);
 
         sph_scalars sc;
         if (sph_get_scalars(ctx, &sc) != SPH_OK) die(ctx, "sph_get_scalars");
+        HostState* fill = &hs;      /* the set the next download goes to */
+        HostState* busy = &hs_alt;  /* the set the writer thread is reading, if one is running */
+        std::thread writer;
         for (int frame = 1; frame <= st.nframes; ++frame) {
             std::cout << "Frame Number: " << frame << "\tError: " << log10(sqrt(sc.errsum / (1.0 * prm.npts))) - sc.logbase
                       << std::endl;
             if (sph_step(ctx, st.npframe, &sc) != SPH_OK) die(ctx, "sph_step");
             if (st.reinit && sph_density_reinit(ctx) != SPH_OK) die(ctx, "sph_density_reinit");
-            if (sph_download(ctx, SPH_STATE_NP1, &h) != SPH_OK) die(ctx, "sph_download");
-            write_frame(hs, f1, sc.t, prm.bound_parts, st.program);
+            if (frame % st.frame_stride != 0 && frame != st.nframes) continue;
+            sph_fields hf = fill->fields();
+            if (sph_download(ctx, SPH_STATE_NP1, &hf) != SPH_OK) die(ctx, "sph_download");
+            if (writer.joinable()) writer.join(); /* frames go to the file in order */
+            const float tframe = sc.t;
+            HostState* job = fill;
+            writer = std::thread([&f1, job, tframe, &prm, &st, nthreads]() {
+                write_frame(*job, f1, tframe, prm.bound_parts, st.program, nthreads);
+            });
+            std::swap(fill, busy);
         }
+        if (writer.joinable()) writer.join();
         f1.close();
     } else {
         std::cerr << "Error opening frame output file." << std::endl;

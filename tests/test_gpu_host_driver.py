@@ -92,3 +92,55 @@ def test_driver_writes_the_reference_outputs(program, name, dim, tmp_path):
         # three decimals, fixed: each printed value is the oracle's value rounded there
         assert np.all(np.abs(got - want) <= 0.5e-3 + 1e-9 * np.maximum(1.0, np.abs(want))), fi
         assert np.mean(np.abs(got - np.round(want, 3)) < 1e-9) > 0.999
+
+
+def _run(tmp_path, tag, extra):
+    spec = util.small_cases()["wcxsph3d_block"]
+    settings = tmp_path / ("in_%s.txt" % tag)
+    fmt = lambda a: " ".join(repr(float(v)) for v in a)
+    settings.write_text("\n".join([
+        "default_params? no", "outfile %s" % (tmp_path / tag), "program WCXSPH3D", "nframes 4", "npframe 5",
+        "dt 0.0002", "psize %r" % spec["pstep"], "simtype Box", "npart " + " ".join(str(v) for v in spec["npart"]),
+        "box " + fmt(spec["box"]), "start " + fmt(spec["start"]), "reinit 1"] + extra + [""]))
+    r = subprocess.run([SPH_RUN, str(settings)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return (tmp_path / (tag + ".plt")).read_bytes()
+
+
+def test_threaded_writer_and_frame_stride(tmp_path):
+    one = _run(tmp_path, "one", ["threads 1"])
+    many = _run(tmp_path, "many", ["threads 7"])
+    assert one == many and one.count(b"ZONE") == 2 * 5
+    # the rows are what iostream's fixed/setprecision(3) prints: three decimals, single spaces
+    row = one.split(b"\n")[2].split(b" ")
+    assert len(row) == 7 and all(len(v.split(b".")[1]) == 3 for v in row)
+    strided = _run(tmp_path, "strided", ["frame_stride 2"])
+    assert strided.count(b"ZONE") == 2 * 3  # frames 0, 2 and 4
+    frames = one.split(b"ZONE t=\"Boundary Data\"")
+    sframes = strided.split(b"ZONE t=\"Boundary Data\"")
+    assert sframes[1] == frames[1] and sframes[2] == frames[3] and sframes[3] == frames[5]
+
+
+def test_droplet_settings(tmp_path):
+    spec = util.drop_cases()["droplet3d"]
+    d = spec["drop"]
+    fmt = lambda a: " ".join(repr(float(v)) for v in a)
+    settings = tmp_path / "drop.txt"
+    settings.write_text("\n".join([
+        "default_params? no", "outfile %s" % (tmp_path / "Drop"), "program WCXSPH3D", "nframes 1", "npframe 5",
+        "psize %r" % spec["pstep"], "npart " + " ".join(str(v) for v in spec["npart"]), "box " + fmt(spec["box"]),
+        "start " + fmt(spec["start"]), "simtype Droplet", "drop_radius %r" % d["radius"],
+        "drop_centre " + fmt(d["centre"]), "drop_velocity " + fmt(d["v"]), ""]))
+    r = subprocess.run([SPH_RUN, str(settings)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    oc, _ = util.both_cases(spec)
+    orc = O.Oracle(oc)
+    orc.forces(O.STATE_N)
+    orc.zero_boundary_f(O.STATE_N)
+    orc.step(5)
+    orc.density_reinit()
+    header, zones = parse_plt(str(tmp_path / "Drop.plt"))
+    got = np.vstack([zones[2][2], zones[3][2]])
+    want = oracle_rows(orc, O.STATE_NP1)
+    assert got.shape == want.shape
+    assert np.all(np.abs(got - want) <= 0.5e-3 + 1e-9 * np.maximum(1.0, np.abs(want)))
