@@ -1472,9 +1472,9 @@ int sph_density_reinit(sph_ctx* c) {
     RI(k_reinit_count, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream);
     hipLaunchKernelGGL(k_reinit_start, dim3(1), dim3(1), 0, c->stream, c->ri_ctl);
     HIPCHK(hipGetLastError());
+    ReinitCtl* h = (ReinitCtl*)c->need_host; /* pinned, 8 words */
     /* one launch per dependency level; the host looks at the queue every so often */
     const int batch = 256, grid = 256; /* one wavefront per released particle, 1024 per pass of the grid */
-    ReinitCtl* h = (ReinitCtl*)c->need_host; /* pinned, 8 words */
     for (uint64_t guard = 0;; ++guard) {
         for (int b = 0; b < batch; ++b) RI(k_reinit_level, dim3(grid), dim3(SPH_BLOCK), 0, c->stream);
         c->reinit_launches += batch;

@@ -1405,114 +1405,125 @@ __device__ __forceinline__ double wave_allsum(double v) {
     return v;
 }
 
+/* DensityReinit of one released particle by one wavefront: the lanes share out its candidates,
+ * partial sums are folded with a fixed butterfly (every lane ends with the same bits), every
+ * lane solves the small system, lane 0 stores rho, and each lane tells `release` about the
+ * waiting neighbours among its candidates whose last dependency this was. */
+template <int DIM, typename Release>
+__device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__ rec, const uint32_t* __restrict__ nbr,
+                                           uint32_t stride, const uint32_t* __restrict__ cnt,
+                                           const uint32_t* __restrict__ id, uint32_t* __restrict__ pend, uint32_t i,
+                                           uint32_t lane, Release release) {
+    constexpr int N = DIM + 1;
+    const Rec ri = rec[i];
+    const uint32_t me = id[i], c = cnt[i];
+    /* Abar (WCXSPH3D.cpp:218-229) is symmetric: its upper triangle, accumulated per lane */
+    double A[N][N];
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int cc = 0; cc < N; ++cc) A[r][cc] = 0.0;
+    auto add_A = [&](const double (&e)[N], double W, double mj, double rhoj) {
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int cc = r; cc < N; ++cc) {
+                const double abar = r == 0 ? e[cc] : e[cc] * e[r];
+                A[r][cc] += W * abar * mj / rhoj;
+            }
+    };
+    if (lane == 0) { /* the particle itself (distance 0) */
+        double e[N];
+        e[0] = 1;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) e[d + 1] = 0.0;
+        add_A(e, w2_kernel(P, 0.0), P.xsph ? (double)ri.m : P.mass, (double)ri.rho);
+    }
+    /* one candidate of the list: in the radius by the search's own distance (xj - xi, as the
+     * search forms it)?  then Rij = xi - xj, W(|Rij|), m_j, rho_j */
+    struct Nb {
+        uint32_t j, idj;
+        bool in;
+        double e[N], W, m, rho;
+    };
+    auto fetch = [&](uint32_t k) {
+        Nb b;
+        b.j = nbr[(size_t)i * stride + k];
+        const Rec rj = rec[b.j];
+        b.idj = id[b.j];
+        const double d2 = dist2_exact(rj.xv[0][0] - ri.xv[0][0], rj.xv[1][0] - ri.xv[1][0],
+                                      DIM == 3 ? rj.xv[2][0] - ri.xv[2][0] : 0.0);
+        b.in = d2 < P.R2;
+        b.e[0] = 1;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) b.e[d + 1] = ri.xv[d][0] - rj.xv[d][0];
+        const double r = sqrt(DIM == 3 ? b.e[1] * b.e[1] + b.e[2] * b.e[2] + b.e[N - 1] * b.e[N - 1]
+                                       : b.e[1] * b.e[1] + b.e[2] * b.e[2]);
+        b.W = w2_kernel(P, r);
+        b.m = P.xsph ? (double)rj.m : P.mass;
+        b.rho = (double)rj.rho;
+        return b;
+    };
+    /* the first 64 candidates stay in registers for the second pass */
+    Nb first;
+    first.in = false;
+    first.j = 0;
+    first.idj = 0;
+    if (lane < c) {
+        first = fetch(lane);
+        if (first.in) add_A(first.e, first.W, first.m, first.rho);
+    }
+    for (uint32_t k = lane + 64; k < c; k += 64) {
+        const Nb b = fetch(k);
+        if (b.in) add_A(b.e, b.W, b.m, b.rho);
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int cc = r; cc < N; ++cc) {
+            A[r][cc] = wave_allsum(A[r][cc]);
+            A[cc][r] = A[r][cc];
+        }
+    const double A00 = A[0][0];
+    double beta[N];
+    if (!fullpiv_solve_e0<N>(A, beta)) { /* Shepard fallback (WCXSPH3D.cpp:235-236) */
+        beta[0] = 1 / A00;
+#pragma unroll
+        for (int d = 1; d < N; ++d) beta[d] = (1 / A00) * 0.0;
+    }
+    /* rho = sum m_j W (beta . (1, Rij)) (WCXSPH3D.cpp:239-247); a finished particle releases
+     * the neighbours that were waiting for it */
+    double rho = 0.0;
+    if (lane == 0) {
+        double poly = beta[0] + beta[1] * 0.0 + beta[2] * 0.0;
+        if (DIM == 3) poly = poly + beta[N - 1] * 0.0;
+        rho += (P.xsph ? (double)ri.m : P.mass) * w2_kernel(P, 0.0) * poly;
+    }
+    auto second = [&](const Nb& b) {
+        if (!b.in) return;
+        double poly = beta[0] + beta[1] * b.e[1] + beta[2] * b.e[2];
+        if (DIM == 3) poly = poly + beta[N - 1] * b.e[N - 1];
+        rho += b.m * b.W * poly;
+        if (b.idj > me && atomicSub(&pend[b.j], 1u) == 1u) release(b.j);
+    };
+    second(first);
+    for (uint32_t k = lane + 64; k < c; k += 64) second(fetch(k));
+    rho = wave_allsum(rho);
+    if (lane == 0) rec[i].rho = (float)rho;
+}
+
 template <int DIM>
 __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_level(DevParams P, Rec* __restrict__ rec,
                                                             const uint32_t* __restrict__ nbr, uint32_t stride,
                                                             const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
                                                             uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
                                                             ReinitCtl* __restrict__ ctl) {
-    constexpr int N = DIM + 1;
     const uint32_t begin = ctl->begin, end = ctl->end;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * SPH_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (SPH_BLOCK / 64);
-    for (uint32_t q = begin + wave; q < end; q += nwaves) {
-        const uint32_t i = queue[q];
-        const Rec ri = rec[i];
-        const uint32_t me = id[i], c = cnt[i];
-        /* Abar (WCXSPH3D.cpp:218-229) is symmetric: its upper triangle, accumulated per lane */
-        double A[N][N];
-#pragma unroll
-        for (int r = 0; r < N; ++r)
-#pragma unroll
-            for (int cc = 0; cc < N; ++cc) A[r][cc] = 0.0;
-        auto add_A = [&](const double (&e)[N], double W, double mj, double rhoj) {
-#pragma unroll
-            for (int r = 0; r < N; ++r)
-#pragma unroll
-                for (int cc = r; cc < N; ++cc) {
-                    const double abar = r == 0 ? e[cc] : e[cc] * e[r];
-                    A[r][cc] += W * abar * mj / rhoj;
-                }
-        };
-        if (lane == 0) { /* the particle itself (distance 0) */
-            double e[N];
-            e[0] = 1;
-#pragma unroll
-            for (int d = 0; d < DIM; ++d) e[d + 1] = 0.0;
-            add_A(e, w2_kernel(P, 0.0), P.xsph ? (double)ri.m : P.mass, (double)ri.rho);
-        }
-        /* one candidate of the list: in the radius by the search's own distance (xj - xi, as the
-         * search forms it)?  then Rij = xi - xj, W(|Rij|), m_j, rho_j */
-        struct Nb {
-            uint32_t j, idj;
-            bool in;
-            double e[N], W, m, rho;
-        };
-        auto fetch = [&](uint32_t k) {
-            Nb b;
-            b.j = nbr[(size_t)i * stride + k];
-            const Rec rj = rec[b.j];
-            b.idj = id[b.j];
-            const double d2 = dist2_exact(rj.xv[0][0] - ri.xv[0][0], rj.xv[1][0] - ri.xv[1][0],
-                                          DIM == 3 ? rj.xv[2][0] - ri.xv[2][0] : 0.0);
-            b.in = d2 < P.R2;
-            b.e[0] = 1;
-#pragma unroll
-            for (int d = 0; d < DIM; ++d) b.e[d + 1] = ri.xv[d][0] - rj.xv[d][0];
-            const double r = sqrt(DIM == 3 ? b.e[1] * b.e[1] + b.e[2] * b.e[2] + b.e[N - 1] * b.e[N - 1]
-                                           : b.e[1] * b.e[1] + b.e[2] * b.e[2]);
-            b.W = w2_kernel(P, r);
-            b.m = P.xsph ? (double)rj.m : P.mass;
-            b.rho = (double)rj.rho;
-            return b;
-        };
-        /* the first 64 candidates stay in registers for the second pass */
-        Nb first;
-        first.in = false;
-        first.j = 0;
-        first.idj = 0;
-        if (lane < c) {
-            first = fetch(lane);
-            if (first.in) add_A(first.e, first.W, first.m, first.rho);
-        }
-        for (uint32_t k = lane + 64; k < c; k += 64) {
-            const Nb b = fetch(k);
-            if (b.in) add_A(b.e, b.W, b.m, b.rho);
-        }
-#pragma unroll
-        for (int r = 0; r < N; ++r)
-#pragma unroll
-            for (int cc = r; cc < N; ++cc) {
-                A[r][cc] = wave_allsum(A[r][cc]);
-                A[cc][r] = A[r][cc];
-            }
-        const double A00 = A[0][0];
-        double beta[N];
-        if (!fullpiv_solve_e0<N>(A, beta)) { /* Shepard fallback (WCXSPH3D.cpp:235-236) */
-            beta[0] = 1 / A00;
-#pragma unroll
-            for (int d = 1; d < N; ++d) beta[d] = (1 / A00) * 0.0;
-        }
-        /* rho = sum m_j W (beta . (1, Rij)) (WCXSPH3D.cpp:239-247); a finished particle releases
-         * the neighbours that were waiting for it */
-        double rho = 0.0;
-        if (lane == 0) {
-            double poly = beta[0] + beta[1] * 0.0 + beta[2] * 0.0;
-            if (DIM == 3) poly = poly + beta[N - 1] * 0.0;
-            rho += (P.xsph ? (double)ri.m : P.mass) * w2_kernel(P, 0.0) * poly;
-        }
-        auto second = [&](const Nb& b) {
-            if (!b.in) return;
-            double poly = beta[0] + beta[1] * b.e[1] + beta[2] * b.e[2];
-            if (DIM == 3) poly = poly + beta[N - 1] * b.e[N - 1];
-            rho += b.m * b.W * poly;
-            if (b.idj > me && atomicSub(&pend[b.j], 1u) == 1u) queue[atomicAdd(&ctl->tail, 1u)] = b.j;
-        };
-        second(first);
-        for (uint32_t k = lane + 64; k < c; k += 64) second(fetch(k));
-        rho = wave_allsum(rho);
-        if (lane == 0) rec[i].rho = (float)rho;
-    }
+    for (uint32_t q = begin + wave; q < end; q += nwaves)
+        reinit_one<DIM>(P, rec, nbr, stride, cnt, id, pend, queue[q], lane,
+                        [&](uint32_t j) { queue[atomicAdd(&ctl->tail, 1u)] = j; });
     /* the block that finishes last hands the next frontier to the next launch */
     __syncthreads();
     if (threadIdx.x == 0) {
