@@ -189,6 +189,11 @@ int sph_upload_global_ids(sph_ctx* ctx, const uint32_t* gids);
  * sph_download_global_ids reports (entry k belongs to the particle with that global index). */
 int sph_local_count(sph_ctx* ctx, uint64_t* npts, uint64_t* migrated_in, uint64_t* migrated_out);
 int sph_download_global_ids(sph_ctx* ctx, uint32_t* gids);
+/* Moves this rank's x-interval (all ranks call it with planes that still tile the line).  With
+ * migrate on, the particles now outside the interval are handed over at the next step's list
+ * rebuild; a particle travels one slab per rebuild, so move a plane by less than a slab, and by
+ * no more particles than the per-side room allows (see capacity). */
+int sph_set_slab_interval(sph_ctx* ctx, double slab_lo, double slab_hi);
 /* A transport over RCCL (ncclSend/ncclRecv/ncclAllReduce on the context's device).
  * `unique_id` is the 128-byte ncclUniqueId, identical on all ranks (rank 0 obtains it with
  * sph_rccl_unique_id and the launcher broadcasts it). */

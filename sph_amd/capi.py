@@ -26,6 +26,7 @@ SYMBOLS = (
     "sph_case_default", "sph_case_params", "sph_case_init",
     "sph_set_transport", "sph_upload_global_ids", "sph_rccl_unique_id", "sph_use_rccl",
     "sph_case_init_range", "sph_case_histogram_x", "sph_local_count", "sph_download_global_ids",
+    "sph_set_slab_interval",
 )
 
 
@@ -119,6 +120,7 @@ def lib():
     L.sph_upload_global_ids.argtypes = [vp, vp]
     L.sph_local_count.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sph_download_global_ids.argtypes = [vp, vp]
+    L.sph_set_slab_interval.argtypes = [vp, C.c_double, C.c_double]
     L.sph_rccl_unique_id.argtypes = [vp]
     L.sph_use_rccl.argtypes = [vp, vp]
     L.sph_case_init_range.argtypes = [C.POINTER(Case), C.c_double, C.c_double, C.POINTER(Fields), vp,
@@ -322,6 +324,9 @@ class Sim:
         n, mi, mo = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._chk(lib().sph_local_count(self._h, C.byref(n), C.byref(mi), C.byref(mo)), "sph_local_count")
         return int(n.value), int(mi.value), int(mo.value)
+
+    def set_slab_interval(self, lo, hi):
+        self._chk(lib().sph_set_slab_interval(self._h, lo, hi), "sph_set_slab_interval")
 
     def download_global_ids(self):
         g = np.zeros(self.npts, np.uint32)

@@ -1288,6 +1288,16 @@ int sph_local_count(sph_ctx* c, uint64_t* npts, uint64_t* migrated_in, uint64_t*
     return SPH_OK;
 }
 
+int sph_set_slab_interval(sph_ctx* c, double slab_lo, double slab_hi) {
+    if (!c) return SPH_EINVAL;
+    if (!c->dist) return fail(c, SPH_ESTATE, "slab intervals are only used when nranks > 1");
+    if (!(slab_hi > slab_lo)) return fail(c, SPH_EINVAL, "empty slab interval");
+    c->prm.slab_lo = slab_lo;
+    c->prm.slab_hi = slab_hi;
+    c->list_valid = false; /* the next step rebuilds its lists and, with migrate on, hands particles over */
+    return SPH_OK;
+}
+
 int sph_download_global_ids(sph_ctx* c, uint32_t* gids) {
     if (!c || !gids) return SPH_EINVAL;
     if (!c->dist) return fail(c, SPH_ESTATE, "global ids are only used when nranks > 1");

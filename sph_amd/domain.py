@@ -129,6 +129,7 @@ class SlabSim(capi.Sim):
         for k, v in overrides.items():
             setattr(p, k, v)
         sim = cls(p)
+        sim._npts0 = n
         sim.global_ids = gids
         sim.npts_global = int(p.npts_global)
         sim.upload(capi.STATE_N, st)
@@ -148,6 +149,52 @@ class SlabSim(capi.Sim):
         sc = super().step(nsteps)
         self.refresh()
         return sc
+
+    def rebalance(self, dist, group=None, wall_weight=0.4, nbins=4096, max_fraction=0.5):
+        """Collective: move the planes towards equal weighted particle counts, judged on where
+        the particles are now.  A plane moves at most as far as `max_fraction` of the per-side
+        hand-over room allows (particles change owner one slab per list rebuild), so a large
+        imbalance is worked off over several calls.  Needs migrate on.  Returns the planes."""
+        x = self.download(capi.STATE_NP1, names=("x",))["x"][0]
+        wall = self.global_ids < self.bound_parts
+        lohi = [None] * self.params.nranks
+        dist.all_gather_object(lohi, (float(x.min()), float(x.max()), float(self.params.slab_lo),
+                                      float(self.params.slab_hi)), group=group)
+        lo = min(v[0] for v in lohi)
+        hi = max(v[1] for v in lohi)
+        edges = np.linspace(lo, hi + 1e-9 * max(1.0, abs(hi)), nbins + 1)
+        h = np.histogram(x, bins=edges, weights=np.where(wall, wall_weight, 1.0))[0]
+        cnt = np.histogram(x, bins=edges)[0].astype(np.float64)
+        both = [None] * self.params.nranks
+        dist.all_gather_object(both, (h, cnt), group=group)
+        h = sum(b[0] for b in both)
+        cnt = sum(b[1] for b in both)
+        cum, ccum = np.cumsum(h), np.cumsum(cnt)
+        nranks, rank = self.params.nranks, self.params.rank
+        room = max_fraction * (int(self.params.capacity) - self._npts0) / 4.0
+        planes = [lohi[0][2]]
+        for r in range(1, nranks):
+            old = lohi[r][2]
+            want = float(edges[min(int(np.searchsorted(cum, cum[-1] * r / nranks)) + 1, nbins)])
+            # particles between the old and the wanted plane may not exceed the room: walk back
+            def between(a, b):
+                ia, ib = sorted((int(np.searchsorted(edges, a)), int(np.searchsorted(edges, b))))
+                return ccum[min(ib, nbins) - 1] - (ccum[ia - 1] if ia > 0 else 0.0) if ib > ia else 0.0
+            new = want
+            for _ in range(40):
+                if between(old, new) <= room:
+                    break
+                new = 0.5 * (old + new)
+            else:
+                new = old
+            planes.append(new)
+        planes.append(lohi[-1][3])
+        for a, b in zip(planes[:-1], planes[1:]):
+            if not b > a:
+                return [v[2] for v in lohi] + [lohi[-1][3]]  # no change rather than an empty slab
+        self.set_slab_interval(planes[rank], planes[rank + 1])
+        self.params.slab_lo, self.params.slab_hi = planes[rank], planes[rank + 1]
+        return planes
 
 
 def gather_state(sim, state, dist, group=None):

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--jitter", type=float, default=0.0)
     ap.add_argument("--vx", type=float, default=0.0, help="initial x-velocity of the fluid")
     ap.add_argument("--migrate", type=int, default=1)
+    ap.add_argument("--even-planes", type=int, default=0, help="cut the box evenly in x instead of by load")
+    ap.add_argument("--rebalance", type=int, default=0, help="re-cut the planes every this many steps")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
 
@@ -35,7 +37,11 @@ def main():
     else:
         case = capi.default_case(spec["program"])
     over = {"skin_frac": args.skin} if args.skin > 0 else {}
-    sim = domain.SlabSim.from_case(case, rank, world, device=0, migrate=bool(args.migrate), **over)
+    planes = None
+    if args.even_planes:
+        planes = [-np.inf] + [case.box[0] * r / world for r in range(1, world)] + [np.inf]
+    sim = domain.SlabSim.from_case(case, rank, world, planes=planes, device=0, migrate=bool(args.migrate),
+                                   halo_room=(1 << 12) if args.rebalance else None, **over)
     tr = domain.HostTransport(rank, world)
     sim.set_transport(tr.struct)
     if args.jitter > 0:
@@ -64,7 +70,18 @@ def main():
     rows = [None] * world
     dist.all_gather_object(rows, (sim.global_ids, offs, cols))
     sim.zero_boundary_forces(capi.STATE_N)
-    sc = sim.step(args.steps)
+    counts_before = [None] * world
+    dist.all_gather_object(counts_before, sim.npts)
+    if args.rebalance:
+        done = 0
+        while done < args.steps:
+            k = min(args.rebalance, args.steps - done)
+            sc = sim.step(k)
+            done += k
+            if done < args.steps:
+                sim.rebalance(dist)
+    else:
+        sc = sim.step(args.steps)
     st = sim.download(capi.STATE_N)
     g1 = domain.gather_state(sim, st, dist)
     if rank == 0:
@@ -90,6 +107,7 @@ def main():
     dist.all_gather_object(moved, (sim.npts, getattr(sim, "migrated_in", 0), getattr(sim, "migrated_out", 0)))
     if rank == 0:
         res["moved"] = np.array(moved)
+        res["counts_before"] = np.array(counts_before)
         np.savez(args.out, **res)
     if tr.error is not None:
         raise tr.error
