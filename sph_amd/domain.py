@@ -222,6 +222,17 @@ def bench_main(args, world, rank, local_rank, fluid):
     import bench as B
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # a transport that never returns must not hold the node for ever: give up loudly
+    import threading
+
+    def give_up():
+        print("rank %d: bench did not finish within %d s, giving up" % (rank, limit_s), file=sys.stderr, flush=True)
+        os._exit(3)
+
+    limit_s = int(os.environ.get("SPH_BENCH_LIMIT_S", "900"))
+    watchdog = threading.Timer(limit_s, give_up)
+    watchdog.daemon = True
+    watchdog.start()
     # control plane (id broadcast, barriers, timing) on gloo; particle data moves over RCCL
     dist.init_process_group("gloo", rank=rank, world_size=world)
     nx, ny, nz = fluid
@@ -321,3 +332,4 @@ def bench_main(args, world, rank, local_rank, fluid):
     sim.close()
     dist.barrier()
     dist.destroy_process_group()
+    watchdog.cancel()
