@@ -243,11 +243,11 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
         if (c->dim == 3)
-            hipLaunchKernelGGL(k_build_list<3>, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, c->n, c->grid, c->cbeg,
+            hipLaunchKernelGGL(k_build_list<3>, dim3((c->n + 63u) / 64u), dim3(SPH_BLOCK), 0, c->stream, r, c->n, c->grid, c->cbeg,
                                c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_ids(c), wall_below,
                                hb, he);
         else
-            hipLaunchKernelGGL(k_build_list<2>, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, c->n, c->grid, c->cbeg,
+            hipLaunchKernelGGL(k_build_list<2>, dim3((c->n + 63u) / 64u), dim3(SPH_BLOCK), 0, c->stream, r, c->n, c->grid, c->cbeg,
                                c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_ids(c), wall_below,
                                hb, he);
         HIPCHK(hipGetLastError());

@@ -381,6 +381,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_walls_at_rest(WallRestArgs a, uin
 /* nbr[i*stride + k], so the rounds of the pair loop walk along cache lines they have already  */
 /* touched (stride is a multiple of 4: every 16-byte group is aligned).                        */
 
+/* Four lanes per particle: the quad walks each neighbouring cell four candidates at a time and
+ * appends the keepers in lane order, so a row lists its candidates cell by cell (x-slowest
+ * offsets), own particles before halo particles, ascending position within a cell. */
 template <int DIM>
 __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict__ rec, uint32_t n, GridParams g,
                                                           const uint32_t* __restrict__ cbeg,
@@ -390,14 +393,17 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
                                                           const uint32_t* __restrict__ id, uint32_t wall_below,
                                                           const uint32_t* __restrict__ hbeg,
                                                           const uint32_t* __restrict__ hend) {
-    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
+    const uint32_t i_raw = blockIdx.x * (SPH_BLOCK / 4) + (threadIdx.x >> 2);
+    const bool active = i_raw < n;
+    const uint32_t i = active ? i_raw : n - 1;
     /* wall_below > 0: pairs of two wall particles are left out (see k_walls_at_rest) */
     const bool i_wall = id[i] < wall_below;
     const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
     const int cx = cell_coord(xi, g.lo[0], g.inv[0], g.n[0]);
     const int cy = cell_coord(yi, g.lo[1], g.inv[1], g.n[1]);
     const int cz = DIM == 3 ? cell_coord(zi, g.lo[2], g.inv[2], g.n[2]) : 0;
+    uint32_t* const row = nbr + (size_t)i * stride;
     uint32_t k = 0;
     for (int dx = -1; dx <= 1; ++dx) {
         const int ax = cx + dx;
@@ -413,23 +419,27 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
                 for (int part = 0; part < (hbeg ? 2 : 1); ++part) {
                     const uint32_t b = part ? hbeg[c] : cbeg[c]; /* empty cell: b = 0xFFFFFFFF, e = 0 */
                     const uint32_t e = part ? hend[c] : cend[c];
-                    for (uint32_t j = b; j < e; ++j) {
-                        if (j == i) continue;
-                        if (i_wall && id[j] < wall_below) continue;
-                        const double dx_ = xi - rec[j].xv[0][0], dy_ = yi - rec[j].xv[1][0];
-                        const double dz_ = DIM == 3 ? zi - rec[j].xv[2][0] : 0.0;
-                        const double d2 = dist2_exact(dx_, dy_, dz_);
-                        if (d2 <= rl2) {
-                            if (k < cap) nbr[(size_t)i * stride + k] = j;
-                            ++k;
+                    for (uint32_t j0 = b; j0 < e; j0 += 4) {
+                        const uint32_t j = j0 + q;
+                        bool keep = false;
+                        if (active && j < e && j != i && !(i_wall && id[j] < wall_below)) {
+                            const double dx_ = xi - rec[j].xv[0][0], dy_ = yi - rec[j].xv[1][0];
+                            const double dz_ = DIM == 3 ? zi - rec[j].xv[2][0] : 0.0;
+                            keep = dist2_exact(dx_, dy_, dz_) <= rl2;
                         }
+                        const uint32_t bits = (uint32_t)(__ballot(keep) >> (lane & 60u)) & 0xFu;
+                        const uint32_t pos = k + __popc(bits & ((1u << q) - 1u));
+                        if (keep && pos < cap) row[pos] = j;
+                        k += __popc(bits);
                     }
                 }
             }
         }
     }
-    cnt[i] = k < cap ? k : cap;
-    if (k > cap) atomicMax(need, k);
+    if (active && q == 0) {
+        cnt[i] = k < cap ? k : cap;
+        if (k > cap) atomicMax(need, k);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------ */
