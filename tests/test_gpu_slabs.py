@@ -170,3 +170,34 @@ def test_planes_are_recut_towards_equal_load(tmp_path):
     print("particles per rank before %s, after %s" % (before, after))
     assert after.max() / after.mean() < before.max() / before.mean()
     assert after.max() / after.mean() < 1.25
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_medium_size_slabs_against_the_single_domain(nranks, tmp_path):
+    # ~0.57 M particles: slabs wide enough to have an interior, so the boundary-first launches,
+    # the overlapped exchange and the interior launch all carry particles.  Reference: the
+    # single-domain HIP path (itself checked against the oracle elsewhere), same bars.
+    from sph_amd import capi
+    spec = dict(program=2, npart=(160, 80, 24), pstep=0.1, box=(32.3, 8.3, 4.8), start=(0.15, 0.15, 0.15))
+    steps = 3
+    res = run_slabs(spec, nranks, tmp_path, steps=steps)
+    _, pc = util.both_cases(spec)
+    sim = capi.Sim.from_case(pc)
+    sim.forces(capi.STATE_N)
+    f0 = sim.download(capi.STATE_N, names=("f", "V", "Rrho"))
+    offs, cols = sim.neighbours(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    sc = sim.step(steps)
+    st = sim.download(capi.STATE_N)
+    assert np.array_equal(res["nbr_offs"], offs.astype(np.int64)) and np.array_equal(res["nbr_cols"], cols)
+    for k in ("f", "V"):
+        assert util.rel_err(res["forces_" + k], f0[k]) <= TOL, k
+    for k in ("x", "v", "V", "f"):
+        assert util.rel_err(res["step_" + k], st[k]) <= TOL, k
+    for k in ("rho", "p"):
+        assert util.float_ulp_diff(res["step_" + k], st[k]).max() <= 1, k
+    dt, t, maxmu, maxf = res["scalars"][:4]
+    assert abs(dt - sc["dt"]) <= 1e-12 * sc["dt"] and abs(maxf - sc["maxf"]) <= 1e-12 * sc["maxf"]
+    assert res["scalars"][6] == sc["hit_pairs"]
+    assert res["per_rank"].min() > 50_000
+    sim.close()
