@@ -101,6 +101,63 @@ class HostTransport:
             return 1
 
 
+class DeviceTransport(HostTransport):
+    """The device-buffer form of the callbacks (host_buffers = 0, as the RCCL transport uses it),
+    moved by hand: wait for the stream, copy to the host, exchange over the process group, copy
+    back.  For ranks that share a GPU, where RCCL refuses to form a communicator."""
+
+    def __init__(self, rank, nranks, group=None):
+        super().__init__(rank, nranks, group)
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self._sr_dev = capi.SENDRECV_FN(self._sendrecv_dev)
+        self._ar_dev = capi.ALLREDUCE_FN(self._allreduce_dev)
+        self.struct = capi.Transport(None, 0, self._sr_dev, self._ar_dev)
+
+    def _to_host(self, dptr, n):
+        buf = (C.c_ubyte * max(n, 1))()
+        if n and self.hip.hipMemcpy(buf, dptr, n, 2) != 0:
+            raise RuntimeError("hipMemcpy D2H failed")
+        return buf
+
+    def _sendrecv_dev(self, user, sL, nsL, rL, nrL, sR, nsR, rR, nrR, stream):
+        try:
+            if self.hip.hipStreamSynchronize(stream) != 0:
+                raise RuntimeError("hipStreamSynchronize failed")
+            hsL, hsR = self._to_host(sL, nsL), self._to_host(sR, nsR)
+            hrL, hrR = (C.c_ubyte * max(nrL, 1))(), (C.c_ubyte * max(nrR, 1))()
+            rc = self._sendrecv(user, C.addressof(hsL), nsL, C.addressof(hrL), nrL, C.addressof(hsR), nsR,
+                                C.addressof(hrR), nrR, None)
+            if rc:
+                return rc
+            for dptr, hbuf, n in ((rL, hrL, nrL), (rR, hrR, nrR)):
+                if n and self.hip.hipMemcpy(dptr, hbuf, n, 1) != 0:
+                    raise RuntimeError("hipMemcpy H2D failed")
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
+
+    def _allreduce_dev(self, user, vals, n, op, stream):
+        try:
+            if self.hip.hipStreamSynchronize(stream) != 0:
+                raise RuntimeError("hipStreamSynchronize failed")
+            dptr = C.cast(vals, C.c_void_p)
+            h = (C.c_double * n)()
+            if self.hip.hipMemcpy(h, dptr, 8 * n, 2) != 0:
+                raise RuntimeError("hipMemcpy D2H failed")
+            rc = self._allreduce(user, C.cast(h, C.POINTER(C.c_double)), n, op, None)
+            if rc:
+                return rc
+            if self.hip.hipMemcpy(dptr, h, 8 * n, 1) != 0:
+                raise RuntimeError("hipMemcpy H2D failed")
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
+
+
 # ---------------------------------------------------------------------------------------------
 
 

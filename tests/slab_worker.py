@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--migrate", type=int, default=1)
     ap.add_argument("--even-planes", type=int, default=0, help="cut the box evenly in x instead of by load")
     ap.add_argument("--rebalance", type=int, default=0, help="re-cut the planes every this many steps")
+    ap.add_argument("--transport", default="host", help="host: host-buffer callbacks; device: device-buffer callbacks")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
 
@@ -42,7 +43,7 @@ def main():
         planes = [-np.inf] + [case.box[0] * r / world for r in range(1, world)] + [np.inf]
     sim = domain.SlabSim.from_case(case, rank, world, planes=planes, device=0, migrate=bool(args.migrate),
                                    halo_room=(1 << 12) if args.rebalance else None, **over)
-    tr = domain.HostTransport(rank, world)
+    tr = domain.DeviceTransport(rank, world) if args.transport == "device" else domain.HostTransport(rank, world)
     sim.set_transport(tr.struct)
     if args.jitter > 0:
         # the same perturbation of the whole set on every rank, then each takes its own rows

@@ -30,7 +30,8 @@ def free_port():
     return port
 
 
-def run_slabs(spec, nranks, tmp_path, steps=2, skin=0.0, jitter=0.0, vx=0.0, migrate=1, even_planes=0, rebalance=0):
+def run_slabs(spec, nranks, tmp_path, steps=2, skin=0.0, jitter=0.0, vx=0.0, migrate=1, even_planes=0, rebalance=0,
+              transport="host"):
     out = str(tmp_path / "slabs.npz")
     port = free_port()
     procs = []
@@ -40,7 +41,7 @@ def run_slabs(spec, nranks, tmp_path, steps=2, skin=0.0, jitter=0.0, vx=0.0, mig
         cmd = [sys.executable, "-u", os.path.join(HERE, "slab_worker.py"), "--spec", json.dumps(spec),
                "--steps", str(steps), "--skin", str(skin), "--jitter", str(jitter), "--vx", str(vx),
                "--migrate", str(migrate), "--even-planes", str(even_planes), "--rebalance", str(rebalance),
-               "--out", out]
+               "--transport", transport, "--out", out]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs, bad = [], False
     for p in procs:
@@ -201,3 +202,14 @@ def test_medium_size_slabs_against_the_single_domain(nranks, tmp_path):
     assert res["scalars"][6] == sc["hit_pairs"]
     assert res["per_rank"].min() > 50_000
     sim.close()
+
+
+@pytest.mark.parametrize("name,nranks,vx", [("wcxsph3d_block", 3, 0.8), ("wcxsph_fine", 2, 0.9)])
+def test_device_buffer_transport(name, nranks, vx, tmp_path):
+    # the callbacks in the form the RCCL transport uses (device pointers plus a stream), with
+    # migration going on: the library side of that path, everything but the RCCL calls themselves
+    spec = util.small_cases()[name]
+    res = run_slabs(spec, nranks, tmp_path, steps=12, skin=0.004, vx=vx, transport="device")
+    orc, f0, nb = oracle_run(spec, 12, vx=vx)
+    check(res, orc, f0, nb, "%s on %d slabs, device-buffer transport" % (name, nranks))
+    assert res["moved"][:, 1].sum() > 0
