@@ -58,7 +58,8 @@ typedef struct sph_params {
     double   mass;             /* the single mass of SPH_VARIANT_WCSPH */
     double   dt0;              /* initial time step (reference: 0.0002) */
     /* Implementation knobs; 0 selects the default. */
-    double   skin_frac;        /* neighbour-candidate skin as a fraction of the search radius */
+    double   skin_frac;        /* neighbour-candidate skin as a fraction of the search radius;
+                                  0: chosen from the particles' travel per step (starts at 0.05) */
     int32_t  max_neighbours;   /* initial per-particle candidate capacity (grows on demand) */
     int32_t  device;           /* HIP device ordinal; -1 = current device */
     /* Slab decomposition along x, one context per GPU (no counterpart in the reference, which

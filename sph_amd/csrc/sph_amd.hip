@@ -85,6 +85,11 @@ struct sph_ctx {
     double skin_frac = 0.05, r_list2 = 0, disp_limit = 0;
     uint32_t brick_log2 = 2;
     double disp_host = 0;
+    /* The skin follows the motion unless the caller fixed it: step_travel is a running upper
+     * estimate of how far the fastest particle gets in one step (the same number on every rank
+     * of a slab run: it derives from the agreed travel bound). */
+    bool skin_auto = true;
+    double step_travel = 0;
 
     DevScalars* S = nullptr;
     DevScalars* S_host = nullptr; /* pinned */
@@ -553,6 +558,14 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
             lo[d] = std::min(lo[d], c->bbox_host[b * 6 + d]);
             hi[d] = std::max(hi[d], c->bbox_host[b * 6 + 3 + d]);
         }
+    if (c->skin_auto && for_step && c->step_travel > 0) {
+        /* Cost per step ~ pair work, of which (measured) a little under half grows like (1+s)^dim,
+         * + a rebuild (about half a step) every 0.5*s*R/travel steps: least near
+         * s = sqrt(2.2 * travel/R / dim); and lists should serve at least two steps. */
+        const double u = c->step_travel / std::sqrt(c->prm.search_radius_sq);
+        const double s_opt = std::max(std::sqrt(2.2 * u / dim), 5.0 * u);
+        c->skin_frac = std::min(0.5, std::max(0.03, s_opt));
+    }
     const double r_list = std::sqrt(c->prm.search_radius_sq) * (1.0 + c->skin_frac);
     const double reach = r_list * (1.0 + 1e-6); /* halo selection distance beyond a neighbour's extent */
     double thr_send[2] = {0, 0};
@@ -911,9 +924,14 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
         /* mode 0: keep the lists if the travel budget allows; 1: fresh lists at the step's
          * start; 2: fresh lists before every sweep (exact for any motion) */
         const bool inner = mode == 0 && c->inner_frac > 0;
-        if (mode >= 1 || !c->list_valid || !c->lists_for_step ||
-            !(c->disp_host <= (inner ? c->outer_budget : 0.5 * c->disp_limit)))
+        /* what is left of the budget must cover this step: the running estimate of a step's
+         * travel (1.25 x) when there is one, half the budget otherwise */
+        const double budget = inner ? c->outer_budget : c->disp_limit;
+        const bool enough = c->step_travel > 0 ? c->disp_host + 1.25 * c->step_travel <= budget
+                                               : c->disp_host <= 0.5 * budget;
+        if (mode >= 1 || !c->list_valid || !c->lists_for_step || !enough)
             CHK(rebuild(c, c->b0, true, true));
+        const double disp_at_start = c->disp_host; /* 0 after a rebuild */
         c->use_nbr = c->nbr;
         c->use_cnt = c->cnt;
         if (inner) {
@@ -1009,8 +1027,15 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
         }
         c->disp_host = c->S_host->disp;
         if (c->S_host->violation && mode < 2) {
+            /* the step outran its lists: it travelled at least the whole budget */
+            c->step_travel = std::max(c->step_travel, 1.25 * c->disp_limit);
             ++c->redos;
             continue;
+        }
+        if (!partial) {
+            /* mode 2 restarts the bound at every sweep; what it saw is a lower bound then */
+            const double seen = c->disp_host - disp_at_start;
+            if (seen == seen && seen >= 0) c->step_travel = std::max(seen, 0.8 * c->step_travel);
         }
         break;
     }
@@ -1096,7 +1121,10 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     c->own_cap = c->cap - 2 * c->halo_cap;
     c->migrate = c->dist && p->migrate != 0;
     c->npairblocks = pairblocks(c->own_cap) + 24; /* up to three launches per sweep, each padded to 8 */
-    if (p->skin_frac > 0) c->skin_frac = p->skin_frac;
+    if (p->skin_frac > 0) {
+        c->skin_frac = p->skin_frac;
+        c->skin_auto = false;
+    }
     if (p->inner_skin_frac > 0) c->inner_frac = p->inner_skin_frac;
     c->brick_log2 = c->dim == 3 ? 2u : 3u;
     if (const char* e = getenv("SPH_BRICK_LOG2")) c->brick_log2 = (uint32_t)std::min(5, std::max(0, atoi(e)));
