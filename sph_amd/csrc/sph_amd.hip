@@ -515,7 +515,6 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     c->n_halo = 0; /* the neighbours' particles are fetched afresh below */
     uint32_t m_sort = n;
     const uint32_t* drop = nullptr;
-    const uint32_t n_before = n;
     bool renumber = false;
     if (c->dist && c->migrate && may_migrate && src == c->b0) {
         uint32_t n_new = n;
@@ -649,7 +648,6 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     /* the leavers sorted behind every cell; from here on this rank owns n particles */
     c->n = n;
     c->dp.n = n;
-    (void)n_before;
 
     /* physical reorder of every live array */
     ReorderArgs a;

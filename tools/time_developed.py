@@ -6,7 +6,8 @@ import bench
 from sph_amd import capi
 skin = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
 last = int(sys.argv[2]) if len(sys.argv) > 2 else 1200
-sim = capi.Sim.from_case(bench.dam_break_3d(640, 320, 48), skin_frac=skin)
+inner = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+sim = capi.Sim.from_case(bench.dam_break_3d(640, 320, 48), skin_frac=skin, inner_skin_frac=inner)
 sim.forces(capi.STATE_N); sim.zero_boundary_forces(capi.STATE_N)
 done = 0
 for target in [t for t in (20, 200, 600, 1200) if t <= last]:
