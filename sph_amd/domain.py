@@ -376,7 +376,7 @@ def bench_main(args, world, rank, local_rank, fluid):
                             "box %.1fx%.1fx%.1f, %d x-slabs, halo exchange over %s"
                             % (world, nx * world, ny, nz, case.box[0], case.box[1], case.box[2], world,
                                "RCCL send/recv" if transport == "rccl" else "host staging + gloo"),
-                "particles": n, "particles_per_rank": per, "sweeps_per_step": 8,
+                "particles": n, "particles_per_rank": per, "sweeps_per_step": 8, "force_evals_per_s": value * 8,
                 "list_rebuilds": prof["rebuilds"], "step_redos": sc["step_redos"], "setup_s": setup_s,
             },
             "roofline": {
