@@ -404,16 +404,28 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
     const int cy = cell_coord(yi, g.lo[1], g.inv[1], g.n[1]);
     const int cz = DIM == 3 ? cell_coord(zi, g.lo[2], g.inv[2], g.n[2]) : 0;
     uint32_t* const row = nbr + (size_t)i * stride;
+    /* A neighbouring cell is skipped when even its nearest point is out of reach.  Distances in
+     * cell edges: fx is the particle's place inside its cell, the gap to a cell on the low side
+     * is fx, on the high side 1 - fx (never negative, and the bound carries a margin far above
+     * the rounding of fx, so no candidate is lost; a kept cell is tested entry by entry as before). */
+    const double fx = fmin(fmax((xi - g.lo[0]) * g.inv[0] - (double)cx, 0.0), 1.0);
+    const double fy = fmin(fmax((yi - g.lo[1]) * g.inv[1] - (double)cy, 0.0), 1.0);
+    const double fz = DIM == 3 ? fmin(fmax((zi - g.lo[2]) * g.inv[2] - (double)cz, 0.0), 1.0) : 0.0;
+    const double reach2 = rl2 * g.inv[0] * g.inv[0] * (1.0 + 1e-6); /* all axes share one edge */
     uint32_t k = 0;
     for (int dx = -1; dx <= 1; ++dx) {
         const int ax = cx + dx;
         if (ax < 0 || ax >= g.n[0]) continue;
+        const double gx = dx < 0 ? fx : (dx > 0 ? 1.0 - fx : 0.0);
         for (int dy = -1; dy <= 1; ++dy) {
             const int ay = cy + dy;
             if (ay < 0 || ay >= g.n[1]) continue;
+            const double gy = dy < 0 ? fy : (dy > 0 ? 1.0 - fy : 0.0);
             for (int dz = (DIM == 3 ? -1 : 0); dz <= (DIM == 3 ? 1 : 0); ++dz) {
                 const int az = cz + dz;
                 if (DIM == 3 && (az < 0 || az >= g.n[2])) continue;
+                const double gz = dz < 0 ? fz : (dz > 0 ? 1.0 - fz : 0.0);
+                if (gx * gx + gy * gy + gz * gz > reach2) continue;
                 const uint32_t c = cell_key<DIM>(g, ax, ay, az);
                 /* own particles of the cell, then (slab runs) the neighbours' particles in it */
                 for (int part = 0; part < (hbeg ? 2 : 1); ++part) {
