@@ -1,0 +1,61 @@
+"""bench.py keeps its contract: one JSON line from rank 0 with the agreed keys, on one GPU and
+under torch.distributed.run with two ranks (sharing the GPU here, bytes staged through gloo)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _check(line, n_gpus, steps, warmup):
+    d = json.loads(line)
+    assert KEYS <= set(d), KEYS - set(d)
+    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
+    assert d["unit"] == "particle-steps/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["particles"] * steps / (d["ms_per_step"] * steps * 1e-3)) <= 1e-6 * d["value"]
+    return d
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--fluid", "48x24x12", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = _check(lines[0], 1, 2, 1)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "particle-steps/s"
+    assert d["roofline"]["traffic"] is None  # counters were taken on the full-size workload only
+
+
+def test_two_rank_line():
+    env = dict(os.environ, SPH_TRANSPORT="host")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--fluid", "48x24x12", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = _check(lines[0], 2, 2, 1)
+    assert len(d["config"]["particles_per_rank"]) == 2 and sum(d["config"]["particles_per_rank"]) == d["config"]["particles"]
