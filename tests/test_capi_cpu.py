@@ -118,3 +118,11 @@ def test_product_code_does_not_reach_the_oracle():
                 if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", "Makefile")):
                     text = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "libsph_amd.so"))
+    with pytest.raises(capi.SphError) as e:
+        capi.lib()
+    assert "not built" in str(e.value) and "no CPU fallback" in str(e.value)
