@@ -403,3 +403,75 @@ def test_droplet_and_jet_steps(name):
     assert_scalars_close(sc, orc.scalars(), name)
     assert sc["maxmu"] > 0  # the body has reached the pool or the wall: viscosity is at work
     sim.close()
+
+
+# ---- edge cases ------------------------------------------------------------------------------------
+
+def test_coincident_and_isolated_particles():
+    # two fluid particles at one point (r = 0: kernel gradient 0, viscosity denominator 0.01 H^2) and
+    # one far from everything (no neighbour but itself): finite, and as the oracle has it
+    spec = CASES["wcxsph3d_block"]
+    oc, pc = util.both_cases(spec)
+    orc, sim = O.Oracle(oc), capi.Sim.from_case(pc)
+    st = orc.get_state(O.STATE_N)
+    x, v = st["x"].copy(), st["v"].copy()
+    nb = orc.bound_parts
+    x[nb + 1] = x[nb]                       # coincident pair
+    v[nb] = (0.3, 0.0, -0.2)
+    v[nb + 1] = (-0.1, 0.2, 0.0)
+    x[nb + 7] = (1.7, 1.2, 1.05)            # alone in the corner of the box, above the block
+    for w_o, w_g in ((O.STATE_N, capi.STATE_N), (O.STATE_NP1, capi.STATE_NP1)):
+        orc.set_state(w_o, x=x, v=v)
+        sim.upload(w_g, {"x": np.ascontiguousarray(x.T), "v": np.ascontiguousarray(v.T)})
+    go, gc = sim.neighbours(capi.STATE_N)
+    oo, occ = orc.neighbours(O.STATE_N)
+    assert np.array_equal(go, oo) and np.array_equal(gc, occ)
+    assert go[nb + 8] - go[nb + 7] == 1     # only itself
+    orc.forces(O.STATE_N); orc.zero_boundary_f(O.STATE_N)
+    sim.forces(capi.STATE_N); sim.zero_boundary_forces(capi.STATE_N)
+    g = sim.download(capi.STATE_N)
+    assert all(np.isfinite(g[k]).all() for k in g)
+    assert_state_close(g, orc.get_state(O.STATE_N), "coincident/isolated, Forces")
+    orc.step(3)
+    sc = sim.step(3)
+    assert_state_close(sim.download(capi.STATE_N), orc.get_state(O.STATE_N), "coincident/isolated, 3 steps")
+    assert_scalars_close(sc, orc.scalars(), "coincident/isolated")
+    orc.density_reinit(); sim.density_reinit()
+    assert util.float_ulp_diff(sim.download(capi.STATE_NP1)["rho"], orc.get_state(O.STATE_NP1)["rho"]).max() <= 1
+    sim.close()
+
+
+def test_smallest_cases():
+    # one fluid particle in a box; and a 2-D column one particle wide
+    for spec in (dict(program=2, npart=(1, 1, 1), pstep=0.1, box=(0.6, 0.6, 0.6), start=(0.3, 0.3, 0.3)),
+                 dict(program=1, npart=(1, 7), pstep=0.1, box=(1.0, 1.5), start=(0.5, 0.12)),
+                 dict(program=0, npart=(2, 2), pstep=0.1, box=(1.0, 1.0), start=(0.45, 0.11))):
+        orc, sim = start(spec)
+        orc.step(5)
+        sc = sim.step(5)
+        assert_state_close(sim.download(capi.STATE_N), orc.get_state(O.STATE_N), str(spec["npart"]))
+        assert_scalars_close(sc, orc.scalars(), str(spec["npart"]))
+        go, gc = sim.neighbours(capi.STATE_NP1)
+        oo, occ = orc.neighbours(O.STATE_NP1)
+        assert np.array_equal(go, oo) and np.array_equal(gc, occ)
+        sim.close()
+
+
+def test_a_particle_gone_nan_does_not_fault():
+    # the reference only notices NaN when it writes a frame (WCXSPH3D.cpp:422-431); here a NaN position must not
+    # take the neighbour search out of bounds: the step completes and the NaN is there to be found
+    _, pc = util.both_cases(CASES["wcxsph3d_block"])
+    sim = capi.Sim.from_case(pc)
+    p, st = capi.case_init(pc)
+    x = st["x"].copy()
+    x[:, int(p.bound_parts) + 5] = np.nan
+    sim.upload(capi.STATE_N, {"x": x})
+    sim.upload(capi.STATE_NP1, {"x": x})
+    sim.forces(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    sim.step(2)
+    g = sim.download(capi.STATE_NP1, names=("x",))["x"]
+    assert np.isnan(g[:, int(p.bound_parts) + 5]).all()
+    others = np.delete(g, int(p.bound_parts) + 5, axis=1)
+    assert np.isfinite(others[:, : int(p.bound_parts)]).all()
+    sim.close()
