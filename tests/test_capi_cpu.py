@@ -126,3 +126,31 @@ def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):
     with pytest.raises(capi.SphError) as e:
         capi.lib()
     assert "not built" in str(e.value) and "no CPU fallback" in str(e.value)
+
+
+def test_create_rejects_bad_parameters_before_looking_for_a_device():
+    import ctypes as C2
+
+    def code_and_message(mutate):
+        p, _, _ = capi.case_params(capi.default_case(2))
+        mutate(p)
+        h = C2.c_void_p()
+        rc = capi.lib().sph_create(C2.byref(p), C2.byref(h))
+        msg = capi.lib().sph_last_error(h).decode() if h else ""
+        if h:
+            capi.lib().sph_destroy(h)
+        return rc, msg
+
+    for mutate, text in ((lambda p: setattr(p, "dim", 4), "dim must be 2 or 3"),
+                         (lambda p: setattr(p, "npts", 0), "npts out of range"),
+                         (lambda p: setattr(p, "bound_parts", p.npts + 1), "bound_parts > npts"),
+                         (lambda p: setattr(p, "variant", 0), "2-D only"),
+                         (lambda p: setattr(p, "subits", 0), "bad physical constants"),
+                         (lambda p: (setattr(p, "nranks", 2), setattr(p, "rank", 2)), "rank out of range"),
+                         (lambda p: (setattr(p, "nranks", 2), setattr(p, "npts_global", p.npts),
+                                     setattr(p, "capacity", p.npts)), "capacity must exceed npts"),
+                         (lambda p: (setattr(p, "nranks", 2), setattr(p, "npts_global", p.npts),
+                                     setattr(p, "capacity", 2 * p.npts), setattr(p, "slab_lo", 1.0),
+                                     setattr(p, "slab_hi", 1.0)), "empty slab interval")):
+        rc, msg = code_and_message(mutate)
+        assert rc == capi.EINVAL and text in msg, (rc, msg, text)
