@@ -1509,6 +1509,14 @@ int sph_density_reinit(sph_ctx* c) {
     hipLaunchKernelGGL(k_reinit_start, dim3(1), dim3(1), 0, c->stream, c->ri_ctl);
     HIPCHK(hipGetLastError());
     ReinitCtl* h = (ReinitCtl*)c->need_host; /* pinned, 8 words */
+    if (n <= 16384) { /* a small case is walked by one workgroup, level after level */
+        RI(k_reinit_single, dim3(1), dim3(REINIT_SINGLE_THREADS), 0, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (h->begin != n || h->tail != n)
+            return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
+    } else {
     /* one launch per dependency level; the host looks at the queue every so often */
     const int batch = 256, grid = 256; /* one wavefront per released particle, 1024 per pass of the grid */
     for (uint64_t guard = 0;; ++guard) {
@@ -1522,6 +1530,7 @@ int sph_density_reinit(sph_ctx* c) {
             break;
         }
         if (guard > (uint64_t)n / batch + 4) return fail(c, SPH_ESTATE, "density re-initialisation did not finish");
+    }
     }
 #undef RI
     /* p/rho^2 of the records follows the new rho (Forces forms it from p and rho, WCXSPH3D.cpp:180) */

@@ -1558,6 +1558,37 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_level(DevParams P, Rec* __
     }
 }
 
+/* Small cases: the whole walk in ONE workgroup, a workgroup barrier between levels instead of
+ * a launch (all waves share the compute unit's cache, so a level sees the previous level's
+ * stores).  A level with few particles then costs a barrier, not a kernel launch. */
+#define REINIT_SINGLE_THREADS 1024
+template <int DIM>
+__global__ __launch_bounds__(REINIT_SINGLE_THREADS) void k_reinit_single(DevParams P, Rec* __restrict__ rec,
+                                                                         const uint32_t* __restrict__ nbr, uint32_t stride,
+                                                                         const uint32_t* __restrict__ cnt,
+                                                                         const uint32_t* __restrict__ id,
+                                                                         uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
+                                                                         ReinitCtl* __restrict__ ctl) {
+    __shared__ uint32_t s_end;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = REINIT_SINGLE_THREADS / 64;
+    uint32_t begin = 0, end = ctl->end;
+    while (begin < end) { /* uniform: every thread holds the same begin and end */
+        for (uint32_t q = begin + wave; q < end; q += nwaves)
+            reinit_one<DIM>(P, rec, nbr, stride, cnt, id, pend, queue[q], lane,
+                            [&](uint32_t j) { queue[atomicAdd(&ctl->tail, 1u)] = j; });
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x == 0) s_end = __hip_atomic_load(&ctl->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        begin = end;
+        end = s_end;
+    }
+    if (threadIdx.x == 0) {
+        ctl->begin = begin;
+        ctl->end = begin;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* neighbour-set probe: CSR over original indices                                             */
 

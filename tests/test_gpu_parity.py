@@ -353,6 +353,23 @@ def test_frames_with_density_reinit(name):
     assert util.float_ulp_diff(g["rho"], o["rho"]).max() <= 1
 
 
+@pytest.mark.parametrize("spec", [
+    dict(program=1, npart=(170, 110), pstep=0.05, box=(12.0, 7.0), start=(0.06, 0.06)),
+    dict(program=2, npart=(24, 20, 16), pstep=0.1, box=(3.0, 2.4, 2.2), start=(0.15, 0.15, 0.15)),
+], ids=["2d_20k", "3d_22k"])
+def test_density_reinit_beyond_the_one_workgroup_size(spec):
+    # cases of up to 16384 particles are walked by one workgroup; larger ones by one launch per level
+    orc, sim = start(spec)
+    assert orc.npts > 16384
+    orc.step(4)
+    sim.step(4)
+    orc.density_reinit()
+    sim.density_reinit()
+    g, o = sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1)
+    assert util.float_ulp_diff(g["rho"], o["rho"]).max() <= 1
+    sim.close()
+
+
 def test_density_reinit_on_a_uniform_lattice_keeps_rho0_inside():
     # known answer: MLS reproduces a constant field wherever the moment matrix is invertible
     _, pc = util.both_cases(CASES["wcxsph3d_block"])
