@@ -1168,9 +1168,11 @@ int sph_create(const sph_params* p, sph_ctx** out) {
             HIPCHK(hipMemsetAsync(c->nd[q * 3 + k], 0, n * sizeof(double), c->stream));
         }
     for (int q = 0; q < 4; ++q) {
-        CHK(dalloc(c, &c->nfl[q], n));
-        CHK(dalloc(c, &c->nfl_alt[q], n));
-        HIPCHK(hipMemsetAsync(c->nfl[q], 0, n * sizeof(float), c->stream));
+        /* an even count: the pair kernel reads these as aligned pairs of floats */
+        CHK(dalloc(c, &c->nfl[q], n + (n & 1)));
+        CHK(dalloc(c, &c->nfl_alt[q], n + (n & 1)));
+        HIPCHK(hipMemsetAsync(c->nfl[q], 0, (n + (n & 1)) * sizeof(float), c->stream));
+        HIPCHK(hipMemsetAsync(c->nfl_alt[q], 0, (n + (n & 1)) * sizeof(float), c->stream));
     }
     for (int b = 0; b < NREC; ++b) {
         CHK(dalloc(c, &c->rec[b], n));

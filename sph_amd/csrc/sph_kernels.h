@@ -532,10 +532,11 @@ __device__ __forceinline__ double fast_rsq(double x) {
 }
 
 /* sqrt(x) for x >= 0 (zero or normal): x * x^(-1/2) from the hardware estimate refined once,
- * then one correction of the root itself; within one unit in the last place.  The clamp
- * keeps x = 0 (two particles at one point) away from 0 * inf. */
+ * then one correction of the root itself; within one unit in the last place.  The added
+ * 1e-300 changes no x that matters and keeps x = 0 (a particle and itself, or two particles at
+ * one point) away from 0 * inf. */
 __device__ __forceinline__ double fast_sqrt(double x) {
-    double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
+    double y = __builtin_amdgcn_rsq(x + 1e-300);
     const double e = fma(-(0.5 * x) * y, y, 0.5);
     y = fma(y, e, y);
     const double r = x * y;
@@ -557,6 +558,21 @@ __device__ __forceinline__ T stream_load(const T* p) {
 }
 template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
+
+/* a[q] for q in 0..2 by selects (a lane-dependent index into an argument array would go
+ * through memory) */
+template <typename T>
+__device__ __forceinline__ T* pick3(T* const (&a)[3], int q) {
+    T* const a0 = a[0];
+    T* const a1 = a[1];
+    T* const a2 = a[2];
+    return q == 1 ? a1 : (q == 2 ? a2 : a0);
+}
+/* the low (which = 0) or high float of an 8-byte pair that was loaded as a double */
+__device__ __forceinline__ float half_of(double pair, uint32_t which) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(pair);
+    return __uint_as_float(which ? (uint32_t)(b >> 32) : (uint32_t)b);
+}
 
 #ifdef SPH_PHASE_TIMING /* development builds only: where a wave of the pair kernel spends its cycles */
 __device__ unsigned long long g_phase[8];
@@ -649,17 +665,25 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
      * one trip to HBM for all of it instead of a second one after the loop */
     const uint32_t c = active ? stream_load(cnt + i) : 0u;
     const uint4 vhead = fetch_vec(0);
+    const uint4 vhead1 = fetch_vec(1);
+    const uint32_t my_id = id[i];
+    /* Every lane issues the same four 8-byte loads from addresses chosen with selects, and
+     * nothing looks at the values before the loop is over, so all of the above and these are
+     * in flight together.  (An array of pointers indexed by the lane's q would be read from
+     * the argument block in memory first: a second trip.)  Lane 3 takes the aligned pair of
+     * floats that holds its particle's Rrho, and the pair that holds its rho. */
     double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
     if (FUSED) {
-        if (q < DIM) {
-            n0 = stream_load(ns.f[q] + i);
-            n1 = stream_load(ns.v[q] + i);
-            n2 = XSPH ? stream_load(ns.V[q] + i) : 0.0;
-            n3 = stream_load(ns.x[q] + i);
-        } else if (q == 3) {
-            n0 = (double)stream_load(ns.Rrho + i); /* floats travel exactly through double */
-            n1 = (double)stream_load(ns.rho + i);
-        }
+        const double* const pr = (const double*)ns.Rrho + (i >> 1);
+        const double* const pq = (const double*)ns.rho + (i >> 1);
+        const bool comp = q < DIM;
+        const double* const p0 = comp ? pick3(ns.f, q) + i : pr;
+        const double* const p1 = comp ? pick3(ns.v, q) + i : pq;
+        const double* const p3 = comp ? pick3(ns.x, q) + i : pr;
+        n0 = stream_load(p0);
+        n1 = stream_load(p1);
+        if (XSPH) n2 = stream_load(comp ? pick3(ns.V, q) + i : pq);
+        n3 = stream_load(p3);
     }
     /* rounds of four candidates; the trip count is made wave-uniform */
     uint32_t rounds = (c + 3u) >> 2;
@@ -670,7 +694,6 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     double Vs0 = 0.0, Vs1 = 0.0, Vs2 = 0.0;
     double rr = 0.0, mumax = 0.0;
-    uint32_t hits = 0;
 
     /* the four pieces this lane holds of the next round's records */
     uint4 pc0, pc1, pc2, pc3;
@@ -720,8 +743,10 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
         return *(const Rec*)(wstage + q * PAIR_LDS_BLOCK + q * 16 + (lane >> 2) * 64);
     };
 
+    const int my_limit = (int)c - q; /* lane q holds entry 4t+q of round t: valid while 4t < c-q */
+    uint32_t hits = 0;               /* wave total, kept on the scalar side */
     auto pair_term = [&](uint32_t t, const Rec& rj, uint32_t j) {
-        const bool valid = t * 4u + (uint32_t)q < c;
+        const bool valid = (int)(t * 4u) < my_limit;
         const double Rx = rj.xv[0][0] - xi0, Ry = rj.xv[1][0] - xi1;
         const double Rz = DIM == 3 ? rj.xv[2][0] - xi2 : 0.0;
         const double d2 = dist2_exact(Rx, Ry, Rz);
@@ -731,19 +756,19 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
             if (keep) stream_store(row_out + kept + __popc(bits & ((1u << q) - 1u)), j);
             kept += __popc(bits);
         }
-        if (valid && d2 < P.R2) {
-            ++hits;
+        const bool hit = valid && d2 < P.R2;
+        hits += (uint32_t)__popcll(__ballot(hit));
+        if (hit) {
             const double Vx = rj.xv[0][1] - vi0, Vy = rj.xv[1][1] - vi1;
             const double Vz = DIM == 3 ? rj.xv[2][1] - vi2 : 0.0;
             const double r = fast_sqrt(d2);
             const double qq = r * invH;
-            double gs = 0.0, Kern = 0.0;
-            if (qq < 2.0) {
-                const double t1 = 1.0 - 0.5 * qq;
-                const double t2 = t1 * t1;
-                gs = gconst * (t2 * t1);
-                if (XSPH) Kern = (t2 * t2) * (2.0 * qq + 1.0) * P.correc;
-            }
+            /* W2Kernel / W2GradK vanish for q >= 2 (WCXSPH3D.cpp:124,133): the clamp makes the
+             * factor (1 - q/2) an exact zero there */
+            const double t1 = fmax(1.0 - 0.5 * qq, 0.0);
+            const double t2 = t1 * t1;
+            const double gs = gconst * (t2 * t1);
+            const double Kern = XSPH ? (t2 * t2) * (2.0 * qq + 1.0) * P.correc : 0.0;
             const double gx = Rx * gs, gy = Ry * gs, gz = Rz * gs;
             const double rho_j = (double)rj.rho;
             const double cbar = 0.5 * (c_i + sqrtBgam * fast_rsq(rho_j));
@@ -758,8 +783,9 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
             double vg = Vx * gx + Vy * gy;
             if (DIM == 3) vg += Vz * gz;
             if (XSPH) {
-                double pifac = P.alpha * cbar * muij * inv_rho;
-                if (vdotr > 0.0) pifac = 0.0;
+                /* viscosity only for approaching pairs (WCXSPH3D.cpp:175-178): mu has the sign
+                 * of vdotr, and a zero factor gives the same zero */
+                const double pifac = P.alpha * cbar * fmin(muij, 0.0) * inv_rho;
                 const double mj = (double)rj.m;
                 const double sc = mj * (pifac - ri.prr - rj.prr);
                 acc0 += gx * sc;
@@ -771,8 +797,7 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
                 if (DIM == 3) Vs2 += xs * Vz;
                 rr -= mj * vg;
             } else {
-                double pifac = -P.alpha * cbar * muij * inv_rho;
-                if (vdotr > 0.0) pifac = 0.0;
+                const double pifac = -P.alpha * cbar * fmin(muij, 0.0) * inv_rho;
                 const double sc = pifac + ri.prr + rj.prr;
                 acc0 -= gx * sc;
                 acc1 -= gy * sc;
@@ -796,16 +821,21 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
 
     PHASE_MARK(1)
     if (rounds > 0) {
-        uint4 vcur = vhead;
+        /* the entries of rounds 0..7 were requested with the rest up front; those of super-round
+         * u+2 are requested at the top of super-round u, so that the wait for a round's records
+         * (the counter is in order) never includes a row fetch that has just left */
+        uint4 vcur = vhead, vnext = vhead1;
         LOAD_FROM(vcur, 0, 0u)
         const uint32_t nsup = (rounds + 3u) >> 2;
         for (uint32_t u = 0; u < nsup; ++u) {
-            const uint4 vnext = fetch_vec(u + 1);
+            uint4 vafter = vnext;
+            if (u + 2 < nsup) vafter = fetch_vec(u + 2);
             ROUND(0, vcur, 1)
             ROUND(1, vcur, 2)
             ROUND(2, vcur, 3)
             ROUND(3, vnext, 0)
             vcur = vnext;
+            vnext = vafter;
         }
     }
 #undef ROUND
@@ -825,7 +855,7 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
     mumax = quad_max(mumax);
 
     /* lane d finishes component d; lane 3 the scalars */
-    const bool wall = zero_wall && id[i] < P.bound_parts;
+    const bool wall = zero_wall && my_id < P.bound_parts;
     double f2 = 0.0, move2 = 0.0;
     double fd = q == 0 ? acc0 : (q == 1 ? acc1 : acc2);
     double Vd = (q == 0 ? vi0 : (q == 1 ? vi1 : vi2)) + (q == 0 ? Vs0 : (q == 1 ? Vs1 : Vs2));
@@ -839,8 +869,8 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
     if (q >= DIM) fd = 0.0;
     if (active && store_out) {
         if (q < DIM) {
-            stream_store(out.f[q] + i, fd);
-            if (XSPH) stream_store(out.V[q] + i, Vd);
+            stream_store(pick3(out.f, q) + i, fd);
+            if (XSPH) stream_store(pick3(out.V, q) + i, Vd);
         } else if (q == 3) {
             stream_store(out.Rrho + i, Rrho_f);
         }
@@ -864,8 +894,9 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
             const double ex = xnew - (q == 0 ? xi0 : (q == 1 ? xi1 : xi2));
             move2 = ex * ex;
         } else if (q == 3) {
-            const float rsum = (float)n0 + Rrho_f; /* float add, as the reference */
-            const float rho_new = (float)(n1 + hdt * (double)rsum);
+            const float Rrho_n = half_of(n0, i & 1u), rho_n = half_of(n1, i & 1u);
+            const float rsum = Rrho_n + Rrho_f; /* float add, as the reference */
+            const float rho_new = (float)((double)rho_n + hdt * (double)rsum);
             const float p_new = (float)(P.B * tait_pow_m1((double)rho_new / P.rho0, P.gam));
             chunk.f[0] = rho_new;
             chunk.f[1] = ri.m;
@@ -905,11 +936,7 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
         const double wf = quads_max(speak ? f2 : 0.0);
         const double wv = quads_max(speak ? (move2 == move2 ? move2 : 1e300) : 0.0); /* NaN counts as huge */
         const double ws = quads_sum(speak ? move2 : 0.0);
-        /* hits: every lane of the quad counted its own candidates */
-        double wh = (double)hits;
-        wh += quad_perm_d<QP_XOR1>(wh);
-        wh += quad_perm_d<QP_XOR2>(wh);
-        wh = quads_sum(q == 0 ? wh : 0.0);
+        const double wh = (double)hits;
         if (lane == 0) {
             red[wave][0] = wm; red[wave][1] = wf; red[wave][2] = wv; red[wave][3] = ws; red[wave][4] = wh;
         }
