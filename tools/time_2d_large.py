@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sph_amd import capi
 
 PEAK = 8.0e12
-for prog, name, bytes_pp in ((capi.PROGRAM_WCSPH, "WCSPH", 60), (capi.PROGRAM_WCXSPH, "WCXSPH", 80)):
+# algorithmic bytes per particle and sweep of the fused launch: pair stage (60 / 80 B in 2-D) plus
+# the update stage (148 B in 2-D with XSPH, 132 B without the V arrays)
+for prog, name, bytes_pp in ((capi.PROGRAM_WCSPH, "WCSPH", 60 + 132), (capi.PROGRAM_WCXSPH, "WCXSPH", 80 + 148)):
     case = capi.make_case(prog, (4800, 6700), 0.0005, (15.0, 8.0), (0.31, 0.31))
     p, _, _ = capi.case_params(case)
     case.dt0 = 0.3 * p.H / p.Cs
