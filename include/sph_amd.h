@@ -142,7 +142,10 @@ int sph_sweeps(sph_ctx* ctx, int32_t nsweeps, sph_scalars* out);
 int sph_get_scalars(sph_ctx* ctx, sph_scalars* out);
 int sph_set_dt(sph_ctx* ctx, double dt);
 
-/* DensityReinit(particlesh, tree) (WCXSPH3D.cpp:208-249). */
+/* DensityReinit(particlesh, tree) (WCXSPH3D.cpp:208-249; WCXSPH.cpp:204-243; WCSPH.cpp:203-243):
+ * rho of state n+1 in the reference's order, a particle seeing the new rho of its neighbours
+ * with a smaller index.  On a slab-decomposed context the call is collective (every rank makes
+ * it) and the order is that of the global indices. */
 int sph_density_reinit(sph_ctx* ctx);
 
 /* The fixed-radius neighbour sets that Forces() would see for one state, as CSR over

@@ -104,6 +104,7 @@ struct sph_ctx {
     uint32_t *ri_pend = nullptr, *ri_queue = nullptr;
     ReinitCtl* ri_ctl = nullptr;
     uint64_t reinit_launches = 0;
+    uint64_t reinit_rounds = 0; /* slab runs: exchanges of the last density re-initialisation */
 
     uint64_t rebuilds = 0, redos = 0;
     bool uploaded_n = false, uploaded_np1 = false;
@@ -1486,32 +1487,96 @@ int sph_set_dt(sph_ctx* c, double dt) {
 int sph_density_reinit(sph_ctx* c) {
     if (!c) return SPH_EINVAL;
     if (!c->uploaded_np1) return fail(c, SPH_ESTATE, "state was never uploaded");
-    if (c->dist)
-        return fail(c, SPH_ESTATE, "density re-initialisation walks the particles in global index order and is not "
-                                   "available on a slab-decomposed context");
     HIPCHK(hipSetDevice(c->device));
-    const uint32_t n = c->n;
     if (!c->ri_pend) {
         CHK(dalloc(c, &c->ri_pend, c->cap));
         CHK(dalloc(c, &c->ri_queue, c->cap));
         CHK(dalloc(c, &c->ri_ctl, 1));
     }
-    /* complete lists (wall-wall pairs included) on the positions of state n+1 */
+    /* complete lists (wall-wall pairs included) on the positions of state n+1; a slab run
+     * fetches its neighbours' particles with them */
     CHK(rebuild(c, c->b0));
+    const uint32_t n = c->n;
     Rec* r = c->rec[c->b0];
+    const uint32_t* ids = wall_ids(c); /* the walk's order: original index, global in a slab run */
     HIPCHK(hipMemsetAsync(c->ri_ctl, 0, sizeof(ReinitCtl), c->stream));
 #define RI(K, ...)                                                                                              \
     do {                                                                                                        \
-        if (c->dim == 3) hipLaunchKernelGGL(K<3>, __VA_ARGS__, c->dp, r, c->nbr, c->cap_k, c->cnt, c->id,        \
+        if (c->dim == 3) hipLaunchKernelGGL(K<3>, __VA_ARGS__, c->dp, r, c->nbr, c->cap_k, c->cnt, ids,          \
                                             c->ri_pend, c->ri_queue, c->ri_ctl);                                \
-        else hipLaunchKernelGGL(K<2>, __VA_ARGS__, c->dp, r, c->nbr, c->cap_k, c->cnt, c->id, c->ri_pend,       \
+        else hipLaunchKernelGGL(K<2>, __VA_ARGS__, c->dp, r, c->nbr, c->cap_k, c->cnt, ids, c->ri_pend,         \
                                 c->ri_queue, c->ri_ctl);                                                        \
     } while (0)
-    RI(k_reinit_count, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream);
+    uint32_t* touches = c->dist ? c->flags : nullptr;
+    if (c->dim == 3)
+        hipLaunchKernelGGL(k_reinit_count<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k, c->cnt,
+                           ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches);
+    else
+        hipLaunchKernelGGL(k_reinit_count<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k, c->cnt,
+                           ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches);
     hipLaunchKernelGGL(k_reinit_start, dim3(1), dim3(1), 0, c->stream, c->ri_ctl);
     HIPCHK(hipGetLastError());
     ReinitCtl* h = (ReinitCtl*)c->need_host; /* pinned, 8 words */
-    if (n <= 16384) { /* a small case is walked by one workgroup, level after level */
+    if (c->dist) {
+        /* The walk is in global index order, so a particle may wait for one of a neighbouring
+         * rank.  Rounds: every rank walks as far as its own particles allow; the ranks then tell
+         * their neighbours the new rho of the shared particles that are finished, each recounts
+         * the waiting particles next to those, and the walk goes on from the ones set free.
+         * Same values as the walk over the whole domain. */
+        const uint32_t nh = c->nrecv[0] + c->nrecv[1];
+        const size_t hc = c->halo_cap;
+        if (nh) HIPCHK(hipMemsetAsync(c->ri_pend + n, 0, sizeof(uint32_t) * nh, c->stream));
+        const int batch = 16, grid = 256;
+        uint32_t done_before = 0;
+        for (uint64_t round = 0;; ++round) {
+            for (;;) { /* the local walk, until its queue runs dry */
+                for (int b = 0; b < batch; ++b) RI(k_reinit_level, dim3(grid), dim3(SPH_BLOCK), 0, c->stream);
+                c->reinit_launches += batch;
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (h->begin == h->end) break;
+            }
+            const uint32_t done_now = h->begin;
+            /* finished shared particles go to the neighbours */
+            uint2* const sb = (uint2*)c->sendbuf;
+            uint2* const rb = (uint2*)c->recvbuf;
+            for (int side = 0; side < 2; ++side)
+                if (c->nsend[side])
+                    hipLaunchKernelGGL(k_reinit_pack, dim3(nblk(c->nsend[side])), dim3(SPH_BLOCK), 0, c->stream, r, c->ri_pend,
+                                       c->send_idx + side * hc, c->nsend[side], sb + side * hc);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev_packed, c->stream));
+            HIPCHK(hipStreamWaitEvent(c->comm, c->ev_packed, 0));
+            CHK(exchange_bytes(c, sb, (size_t)c->nsend[0] * sizeof(uint2), rb, (size_t)c->nrecv[0] * sizeof(uint2), sb + hc,
+                               (size_t)c->nsend[1] * sizeof(uint2), rb + hc, (size_t)c->nrecv[1] * sizeof(uint2)));
+            HIPCHK(hipEventRecord(c->ev_recvd, c->comm));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_recvd, 0));
+            if (c->nrecv[0])
+                hipLaunchKernelGGL(k_reinit_unpack, dim3(nblk(c->nrecv[0])), dim3(SPH_BLOCK), 0, c->stream, rb, c->halo_pos,
+                                   c->nrecv[0], r, c->ri_pend);
+            if (c->nrecv[1])
+                hipLaunchKernelGGL(k_reinit_unpack, dim3(nblk(c->nrecv[1])), dim3(SPH_BLOCK), 0, c->stream, rb + hc,
+                                   c->halo_pos + c->nrecv[0], c->nrecv[1], r, c->ri_pend);
+            if (c->dim == 3)
+                hipLaunchKernelGGL(k_reinit_rescan<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
+                                   c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches);
+            else
+                hipLaunchKernelGGL(k_reinit_rescan<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
+                                   c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches);
+            hipLaunchKernelGGL(k_reinit_resume, dim3(1), dim3(1), 0, c->stream, c->ri_ctl);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            /* all ranks: particles not finished yet, and whether this round moved anything */
+            double v[2] = {(double)(n - done_now), (double)(done_now - done_before) + (double)(h->tail - done_now)};
+            CHK(allreduce_host(c, v, 2, 1));
+            c->reinit_rounds = round + 1;
+            if (v[0] == 0.0) break;
+            if (v[1] == 0.0) return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
+            done_before = done_now;
+        }
+    } else if (n <= 16384) { /* a small case is walked by one workgroup, level after level */
         RI(k_reinit_single, dim3(1), dim3(REINIT_SINGLE_THREADS), 0, c->stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));

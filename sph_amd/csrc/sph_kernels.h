@@ -1416,26 +1416,83 @@ __device__ __forceinline__ bool fullpiv_solve_e0(double (&lu)[N][N], double (&be
     return true;
 }
 
+/* pend[i] of a finished particle; a waiting one holds the number of unfinished neighbours
+ * inside the radius with a smaller original index */
+#define REINIT_DONE 0x80000000u
+
 /* pend[i] = number of neighbours inside the radius with a smaller original index; particles
- * with none form the first frontier */
+ * with none form the first frontier.  Slab runs (touches != nullptr): `id` holds global
+ * indices, neighbours at positions >= P.n are the adjacent ranks' particles, and touches[i]
+ * says whether particle i has any of those inside the radius. */
 template <int DIM>
 __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_count(DevParams P, const Rec* __restrict__ rec,
                                                             const uint32_t* __restrict__ nbr, uint32_t stride,
                                                             const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
                                                             uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
-                                                            ReinitCtl* __restrict__ ctl) {
+                                                            ReinitCtl* __restrict__ ctl, uint32_t* __restrict__ touches) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= P.n) return;
+    const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
+    const uint32_t me = id[i], c = cnt[i];
+    uint32_t lower = 0, far = 0;
+    for (uint32_t k = 0; k < c; ++k) {
+        const uint32_t j = nbr[(size_t)i * stride + k];
+        const double d2 = dist2_exact(rec[j].xv[0][0] - xi, rec[j].xv[1][0] - yi, DIM == 3 ? rec[j].xv[2][0] - zi : 0.0);
+        if (d2 < P.R2) {
+            if (id[j] < me) ++lower;
+            if (j >= P.n) far = 1;
+        }
+    }
+    pend[i] = lower;
+    if (touches) touches[i] = far;
+    if (lower == 0) queue[atomicAdd(&ctl->tail, 1u)] = i;
+}
+
+/* Slab runs, between two local walks: what the neighbours report of their particles that this
+ * rank sees (new rho, finished or not) and the recount of the waiting particles next to them. */
+__global__ __launch_bounds__(SPH_BLOCK) void k_reinit_pack(const Rec* __restrict__ rec, const uint32_t* __restrict__ pend,
+                                                           const uint32_t* __restrict__ idx, uint32_t m,
+                                                           uint2* __restrict__ out) {
+    const uint32_t k = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t i = idx[k];
+    out[k] = make_uint2(__float_as_uint(rec[i].rho), pend[i] == REINIT_DONE ? 1u : 0u);
+}
+__global__ __launch_bounds__(SPH_BLOCK) void k_reinit_unpack(const uint2* __restrict__ in, const uint32_t* __restrict__ pos,
+                                                             uint32_t m, Rec* __restrict__ rec, uint32_t* __restrict__ pend) {
+    const uint32_t k = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t slot = pos[k];
+    if (in[k].y && pend[slot] != REINIT_DONE) {
+        rec[slot].rho = __uint_as_float(in[k].x);
+        pend[slot] = REINIT_DONE;
+    }
+}
+template <int DIM>
+__global__ __launch_bounds__(SPH_BLOCK) void k_reinit_rescan(DevParams P, const Rec* __restrict__ rec,
+                                                             const uint32_t* __restrict__ nbr, uint32_t stride,
+                                                             const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
+                                                             uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
+                                                             ReinitCtl* __restrict__ ctl, const uint32_t* __restrict__ touches) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= P.n || !touches[i] || pend[i] == REINIT_DONE) return;
     const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
     const uint32_t me = id[i], c = cnt[i];
     uint32_t lower = 0;
     for (uint32_t k = 0; k < c; ++k) {
         const uint32_t j = nbr[(size_t)i * stride + k];
         const double d2 = dist2_exact(rec[j].xv[0][0] - xi, rec[j].xv[1][0] - yi, DIM == 3 ? rec[j].xv[2][0] - zi : 0.0);
-        if (d2 < P.R2 && id[j] < me) ++lower;
+        if (d2 < P.R2 && id[j] < me && pend[j] != REINIT_DONE) ++lower;
     }
+    /* the local walk has run dry, so nothing else touches pend[i] now; a waiting particle's
+     * count was above zero until this recount */
     pend[i] = lower;
     if (lower == 0) queue[atomicAdd(&ctl->tail, 1u)] = i;
+}
+/* the particles queued since the last walk are the next frontier */
+__global__ void k_reinit_resume(ReinitCtl* ctl) {
+    ctl->end = ctl->tail;
+    ctl->ticket = 0;
 }
 
 __global__ void k_reinit_start(ReinitCtl* ctl) {
@@ -1553,12 +1610,16 @@ __device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__
         double poly = beta[0] + beta[1] * b.e[1] + beta[2] * b.e[2];
         if (DIM == 3) poly = poly + beta[N - 1] * b.e[N - 1];
         rho += b.m * b.W * poly;
-        if (b.idj > me && atomicSub(&pend[b.j], 1u) == 1u) release(b.j);
+        /* (a neighbouring rank's particle, at a position >= P.n, is released by its owner) */
+        if (b.idj > me && b.j < P.n && atomicSub(&pend[b.j], 1u) == 1u) release(b.j);
     };
     second(first);
     for (uint32_t k = lane + 64; k < c; k += 64) second(fetch(k));
     rho = wave_allsum(rho);
-    if (lane == 0) rec[i].rho = (float)rho;
+    if (lane == 0) {
+        rec[i].rho = (float)rho;
+        pend[i] = REINIT_DONE;
+    }
 }
 
 template <int DIM>

@@ -65,12 +65,14 @@ class HostTransport:
         import torch.distributed as dist
         self.dist, self.rank, self.nranks, self.group = dist, rank, nranks, group
         self.error = None
+        self.exchanges = 0  # sendrecv calls so far
         self._sr = capi.SENDRECV_FN(self._sendrecv)
         self._ar = capi.ALLREDUCE_FN(self._allreduce)
         self.struct = capi.Transport(None, 1, self._sr, self._ar)
 
     def _sendrecv(self, user, sL, nsL, rL, nrL, sR, nsR, rR, nrR, stream):
         try:
+            self.exchanges += 1
             d, ops = self.dist, []
             if nsL:
                 ops.append(d.P2POp(d.isend, _view(sL, nsL), self.rank - 1, self.group))

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--migrate", type=int, default=1)
     ap.add_argument("--even-planes", type=int, default=0, help="cut the box evenly in x instead of by load")
     ap.add_argument("--rebalance", type=int, default=0, help="re-cut the planes every this many steps")
+    ap.add_argument("--reinit", type=int, default=0, help="DensityReinit after every this many steps")
     ap.add_argument("--transport", default="host", help="host: host-buffer callbacks; device: device-buffer callbacks")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
@@ -81,9 +82,19 @@ def main():
             done += k
             if done < args.steps:
                 sim.rebalance(dist)
+    elif args.reinit:
+        # main()'s frames: steps, then DensityReinit on state n+1 (WCXSPH3D.cpp:475-482)
+        done = 0
+        while done < args.steps:
+            k = min(args.reinit, args.steps - done)
+            sc = sim.step(k)
+            done += k
+            sim.density_reinit()
     else:
         sc = sim.step(args.steps)
     st = sim.download(capi.STATE_N)
+    if args.reinit:
+        st["np1_rho"] = sim.download(capi.STATE_NP1, names=("rho",))["rho"]
     g1 = domain.gather_state(sim, st, dist)
     if rank == 0:
         for k, a in g0.items():

@@ -31,7 +31,7 @@ def free_port():
 
 
 def run_slabs(spec, nranks, tmp_path, steps=2, skin=0.0, jitter=0.0, vx=0.0, migrate=1, even_planes=0, rebalance=0,
-              transport="host"):
+              transport="host", reinit=0):
     out = str(tmp_path / "slabs.npz")
     port = free_port()
     procs = []
@@ -41,7 +41,7 @@ def run_slabs(spec, nranks, tmp_path, steps=2, skin=0.0, jitter=0.0, vx=0.0, mig
         cmd = [sys.executable, "-u", os.path.join(HERE, "slab_worker.py"), "--spec", json.dumps(spec),
                "--steps", str(steps), "--skin", str(skin), "--jitter", str(jitter), "--vx", str(vx),
                "--migrate", str(migrate), "--even-planes", str(even_planes), "--rebalance", str(rebalance),
-               "--transport", transport, "--out", out]
+               "--reinit", str(reinit), "--transport", transport, "--out", out]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs, bad = [], False
     for p in procs:
@@ -213,3 +213,47 @@ def test_device_buffer_transport(name, nranks, vx, tmp_path):
     orc, f0, nb = oracle_run(spec, 12, vx=vx)
     check(res, orc, f0, nb, "%s on %d slabs, device-buffer transport" % (name, nranks))
     assert res["moved"][:, 1].sum() > 0
+
+
+# ---- DensityReinit across slabs ----------------------------------------------------------------
+# The walk is in global index order; a rank's particles may wait for a neighbour's.  Same values
+# as the walk over the whole domain: rho of state n+1 within one float ulp of the oracle's right
+# after the call (the two sum a particle's neighbours in different orders), and the usual bars
+# after the main loop has gone on from there.
+
+@pytest.mark.parametrize("name,nranks", [("wcxsph3d_block", 2), ("wcxsph_fine", 3), ("wcsph_fine", 2)])
+def test_density_reinit_across_slabs(name, nranks, tmp_path):
+    spec = util.small_cases()[name]
+    res = run_slabs(spec, nranks, tmp_path, steps=6, reinit=3)
+    oc, _ = util.both_cases(spec)
+    orc = O.Oracle(oc)
+    orc.forces(O.STATE_N)
+    orc.zero_boundary_f(O.STATE_N)
+    for frame in range(2):
+        orc.step(3)
+        orc.density_reinit()
+    u = util.float_ulp_diff(res["step_np1_rho"], orc.get_state(O.STATE_NP1)["rho"])
+    print("%s on %d slabs: DensityReinit rho max ulp %d, differing %d of %d" % (name, nranks, u.max(), int((u > 0).sum()), len(u)))
+    assert u.max() <= 1
+    o = orc.get_state(O.STATE_N)
+    for k in ("x", "v", "f"):
+        err = util.rel_err(res["step_" + k].T, o[k])
+        assert err <= TOL, "%s after two frames off by %.3e" % (k, err)
+    assert util.float_ulp_diff(res["step_rho"], o["rho"]).max() <= 1
+
+
+def test_density_reinit_across_slabs_with_particles_changing_owner(tmp_path):
+    # a droplet moving in x: particles cross the plane between the frames' re-initialisations
+    spec = util.drop_cases()["droplet3d"]
+    res = run_slabs(spec, 2, tmp_path, steps=6, reinit=2, skin=0.05)
+    oc, _ = util.both_cases(spec)
+    orc = O.Oracle(oc)
+    orc.forces(O.STATE_N)
+    orc.zero_boundary_f(O.STATE_N)
+    for frame in range(3):
+        orc.step(2)
+        orc.density_reinit()
+    assert util.float_ulp_diff(res["step_np1_rho"], orc.get_state(O.STATE_NP1)["rho"]).max() <= 1
+    o = orc.get_state(O.STATE_N)
+    for k in ("x", "v", "f"):
+        assert util.rel_err(res["step_" + k].T, o[k]) <= TOL, k
