@@ -1801,6 +1801,11 @@ int sph_use_rccl(sph_ctx* c, const void* unique_id_128) {
         delete r;
         return SPH_ECOMM;
     }
+    if (c->have_tr) { /* the caller gave up waiting and installed another transport meanwhile */
+        (void)r->CommDestroy(r->comm);
+        delete r;
+        return fail(c, SPH_ESTATE, "another transport was installed while the RCCL communicator was being created");
+    }
     c->rccl = r;
     c->rccl_free = rccl_release;
     sph_transport t;

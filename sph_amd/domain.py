@@ -318,11 +318,23 @@ def bench_main(args, world, rank, local_rank, fluid):
     if transport == "rccl":
         ident = [capi.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
-        why = None
-        try:
-            sim.use_rccl(ident[0])
-        except capi.SphError as e:
-            why = str(e)
+        # creating the communicator is a collective inside RCCL: if it does not return, every
+        # rank gives up after the same time and the run goes on over the staged transport
+        got = {}
+
+        def create():
+            try:
+                sim.use_rccl(ident[0])
+            except capi.SphError as e:
+                got["why"] = str(e)
+
+        wait_s = float(os.environ.get("SPH_RCCL_INIT_S", "120"))
+        th = threading.Thread(target=create, daemon=True)
+        th.start()
+        th.join(wait_s)
+        why = got.get("why")
+        if th.is_alive():
+            why = "ncclCommInitRank did not return within %.0f s" % wait_s
         failed = torch.tensor([1 if why else 0], dtype=torch.int32)
         dist.all_reduce(failed, op=dist.ReduceOp.MAX)
         if int(failed[0]):
