@@ -381,25 +381,45 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_walls_at_rest(WallRestArgs a, uin
 /* nbr[i*stride + k], so the rounds of the pair loop walk along cache lines they have already  */
 /* touched (stride is a multiple of 4: every 16-byte group is aligned).                        */
 
+/* What the list build reads of a candidate, 32 bytes instead of three pieces of a 64-byte
+ * record and a word of the index array: four consecutive candidates are 128 contiguous bytes
+ * (the vector-memory pipe is paced by the distinct segments an instruction touches). */
+struct __attribute__((aligned(32))) Pos {
+    double x, y, z;
+    uint32_t id, pad;
+};
+__global__ __launch_bounds__(SPH_BLOCK) void k_fill_pos(const Rec* __restrict__ rec, const uint32_t* __restrict__ id, uint32_t m,
+                                                        Pos* __restrict__ pos) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    Pos p;
+    p.x = rec[i].xv[0][0];
+    p.y = rec[i].xv[1][0];
+    p.z = rec[i].xv[2][0];
+    p.id = id[i];
+    p.pad = 0;
+    pos[i] = p;
+}
+
 /* Four lanes per particle: the quad walks each neighbouring cell four candidates at a time and
  * appends the keepers in lane order, so a row lists its candidates cell by cell (x-slowest
  * offsets), own particles before halo particles, ascending position within a cell. */
 template <int DIM>
-__global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict__ rec, uint32_t n, GridParams g,
+__global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Pos* __restrict__ pos, uint32_t n, GridParams g,
                                                           const uint32_t* __restrict__ cbeg,
                                                           const uint32_t* __restrict__ cend, double rl2,
                                                           uint32_t* __restrict__ nbr, uint32_t stride, uint32_t cap,
                                                           uint32_t* __restrict__ cnt, uint32_t* __restrict__ need,
-                                                          const uint32_t* __restrict__ id, uint32_t wall_below,
-                                                          const uint32_t* __restrict__ hbeg,
+                                                          uint32_t wall_below, const uint32_t* __restrict__ hbeg,
                                                           const uint32_t* __restrict__ hend) {
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
     const uint32_t i_raw = blockIdx.x * (SPH_BLOCK / 4) + (threadIdx.x >> 2);
     const bool active = i_raw < n;
     const uint32_t i = active ? i_raw : n - 1;
     /* wall_below > 0: pairs of two wall particles are left out (see k_walls_at_rest) */
-    const bool i_wall = id[i] < wall_below;
-    const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
+    const Pos pi = pos[i];
+    const bool i_wall = pi.id < wall_below;
+    const double xi = pi.x, yi = pi.y, zi = DIM == 3 ? pi.z : 0.0;
     const int cx = cell_coord(xi, g.lo[0], g.inv[0], g.n[0]);
     const int cy = cell_coord(yi, g.lo[1], g.inv[1], g.n[1]);
     const int cz = DIM == 3 ? cell_coord(zi, g.lo[2], g.inv[2], g.n[2]) : 0;
@@ -434,14 +454,15 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
                     for (uint32_t j0 = b; j0 < e; j0 += 4) {
                         const uint32_t j = j0 + q;
                         bool keep = false;
-                        if (active && j < e && j != i && !(i_wall && id[j] < wall_below)) {
-                            const double dx_ = xi - rec[j].xv[0][0], dy_ = yi - rec[j].xv[1][0];
-                            const double dz_ = DIM == 3 ? zi - rec[j].xv[2][0] : 0.0;
-                            keep = dist2_exact(dx_, dy_, dz_) <= rl2;
+                        if (active && j < e && j != i) {
+                            const Pos pj = pos[j];
+                            const double dx_ = xi - pj.x, dy_ = yi - pj.y;
+                            const double dz_ = DIM == 3 ? zi - pj.z : 0.0;
+                            keep = dist2_exact(dx_, dy_, dz_) <= rl2 && !(i_wall && pj.id < wall_below);
                         }
                         const uint32_t bits = (uint32_t)(__ballot(keep) >> (lane & 60u)) & 0xFu;
-                        const uint32_t pos = k + __popc(bits & ((1u << q) - 1u));
-                        if (keep && pos < cap) row[pos] = j;
+                        const uint32_t at = k + __popc(bits & ((1u << q) - 1u));
+                        if (keep && at < cap) row[at] = j;
                         k += __popc(bits);
                     }
                 }
