@@ -249,15 +249,16 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
     /* positions and wall ids of the owned and the neighbours' particles, packed for the build
      * (in the spare record array, which nothing else uses between a reorder and the next one) */
     const uint32_t m = c->n + c->n_halo;
-    hipLaunchKernelGGL(k_fill_pos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, wall_ids(c), m, (Pos*)c->rec_alt);
+    hipLaunchKernelGGL(k_fill_pos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, wall_ids(c), m, c->grid, c->dim,
+                       (Pos*)c->rec_alt);
     const Pos* pos = (const Pos*)c->rec_alt;
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
         if (c->dim == 3)
-            hipLaunchKernelGGL(k_build_list<3>, dim3((c->n + 63u) / 64u), dim3(SPH_BLOCK), 0, c->stream, pos, c->n, c->grid, c->cbeg,
+            hipLaunchKernelGGL(k_build_list<3>, dim3((c->n + 63u) / 64u), dim3(SPH_BLOCK), 0, c->stream, r, pos, c->n, c->grid, c->cbeg,
                                c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below, hb, he);
         else
-            hipLaunchKernelGGL(k_build_list<2>, dim3((c->n + 63u) / 64u), dim3(SPH_BLOCK), 0, c->stream, pos, c->n, c->grid, c->cbeg,
+            hipLaunchKernelGGL(k_build_list<2>, dim3((c->n + 63u) / 64u), dim3(SPH_BLOCK), 0, c->stream, r, pos, c->n, c->grid, c->cbeg,
                                c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below, hb, he);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

@@ -376,28 +376,38 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_walls_at_rest(WallRestArgs a, uin
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* candidate lists: every j != i with |xi-xj|^2 <= rl2 at build time, in cell-range order     */
+/* candidate lists: every j != i with |xi-xj|^2 <= rl2 at build time (and the few the float  */
+/* test lets in just beyond), in cell-range order                                            */
 /* then ascending j.  One row of `stride` entries per particle: entry k of particle i sits at  */
 /* nbr[i*stride + k], so the rounds of the pair loop walk along cache lines they have already  */
 /* touched (stride is a multiple of 4: every 16-byte group is aligned).                        */
 
-/* What the list build reads of a candidate, 32 bytes instead of three pieces of a 64-byte
- * record and a word of the index array: four consecutive candidates are 128 contiguous bytes
- * (the vector-memory pipe is paced by the distinct segments an instruction touches). */
-struct __attribute__((aligned(32))) Pos {
-    double x, y, z;
-    uint32_t id, pad;
+/* What the list build reads of a candidate: 16 bytes, its position inside its cell as floats
+ * (distance from the cell's low corner, formed in double and rounded once) and its wall index,
+ * instead of three pieces of a 64-byte record and a word of the index array -- four consecutive
+ * candidates are 64 contiguous bytes (the vector-memory pipe is paced by the distinct segments
+ * an instruction touches), and the test is single-precision arithmetic.
+ *
+ * The lists only have to CONTAIN every pair within the list radius; the pair kernel decides
+ * membership exactly.  With both ends inside their cells (|u| <= edge) the float distance of a
+ * pair of particles one cell apart is off by less than 1e-6 of the cell edge per component
+ * (two roundings to float of values <= edge, the float edge, two subtractions of values
+ * <= 2 edges), its square by less than 3e-6 of edge^2; the build keeps d^2 <= (1 + 4e-5) rl^2. */
+struct __attribute__((aligned(16))) Pos {
+    float u, v, w;
+    uint32_t id;
 };
+#define LIST_FLOAT_MARGIN 4e-5
 __global__ __launch_bounds__(SPH_BLOCK) void k_fill_pos(const Rec* __restrict__ rec, const uint32_t* __restrict__ id, uint32_t m,
-                                                        Pos* __restrict__ pos) {
+                                                        GridParams g, int dim, Pos* __restrict__ pos) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= m) return;
+    const double x = rec[i].xv[0][0], y = rec[i].xv[1][0], z = rec[i].xv[2][0];
     Pos p;
-    p.x = rec[i].xv[0][0];
-    p.y = rec[i].xv[1][0];
-    p.z = rec[i].xv[2][0];
+    p.u = (float)((x - g.lo[0]) - (double)cell_coord(x, g.lo[0], g.inv[0], g.n[0]) * (1.0 / g.inv[0]));
+    p.v = (float)((y - g.lo[1]) - (double)cell_coord(y, g.lo[1], g.inv[1], g.n[1]) * (1.0 / g.inv[1]));
+    p.w = dim == 3 ? (float)((z - g.lo[2]) - (double)cell_coord(z, g.lo[2], g.inv[2], g.n[2]) * (1.0 / g.inv[2])) : 0.0f;
     p.id = id[i];
-    p.pad = 0;
     pos[i] = p;
 }
 
@@ -405,7 +415,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_fill_pos(const Rec* __restrict__ 
  * appends the keepers in lane order, so a row lists its candidates cell by cell (x-slowest
  * offsets), own particles before halo particles, ascending position within a cell. */
 template <int DIM>
-__global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Pos* __restrict__ pos, uint32_t n, GridParams g,
+__global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict__ rec, const Pos* __restrict__ pos, uint32_t n,
+                                                          GridParams g,
                                                           const uint32_t* __restrict__ cbeg,
                                                           const uint32_t* __restrict__ cend, double rl2,
                                                           uint32_t* __restrict__ nbr, uint32_t stride, uint32_t cap,
@@ -419,7 +430,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Pos* __restrict_
     /* wall_below > 0: pairs of two wall particles are left out (see k_walls_at_rest) */
     const Pos pi = pos[i];
     const bool i_wall = pi.id < wall_below;
-    const double xi = pi.x, yi = pi.y, zi = DIM == 3 ? pi.z : 0.0;
+    const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
+    const float edge = (float)(1.0 / g.inv[0]); /* all axes share one edge */
+    const float rl2f = (float)(rl2 * (1.0 + LIST_FLOAT_MARGIN));
     const int cx = cell_coord(xi, g.lo[0], g.inv[0], g.n[0]);
     const int cy = cell_coord(yi, g.lo[1], g.inv[1], g.n[1]);
     const int cz = DIM == 3 ? cell_coord(zi, g.lo[2], g.inv[2], g.n[2]) : 0;
@@ -433,40 +446,64 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Pos* __restrict_
     const double fz = DIM == 3 ? fmin(fmax((zi - g.lo[2]) * g.inv[2] - (double)cz, 0.0), 1.0) : 0.0;
     const double reach2 = rl2 * g.inv[0] * g.inv[0] * (1.0 + 1e-6); /* all axes share one edge */
     uint32_t k = 0;
+    /* The quad tests the particles [b, e) eight at a time (two per lane, both fetches in flight
+     * together) and appends the keepers in ascending order.  Empty range: b = 0xFFFFFFFF, e = 0. */
+    auto walk = [&](uint32_t b, uint32_t e, float bx, float by, float bz) {
+        for (uint32_t j0 = b; j0 < e; j0 += 8) {
+            const uint32_t ja = j0 + q, jb = j0 + 4u + q;
+            const Pos pa = pos[ja < e ? ja : i], pb = pos[jb < e ? jb : i]; /* whole entries, no second fetch */
+            const float ax_ = bx - pa.u, ay_ = by - pa.v, az_ = DIM == 3 ? bz - pa.w : 0.0f;
+            const float cx_ = bx - pb.u, cy_ = by - pb.v, cz_ = DIM == 3 ? bz - pb.w : 0.0f;
+            const float d2a = ax_ * ax_ + ay_ * ay_ + az_ * az_;
+            const float d2b = cx_ * cx_ + cy_ * cy_ + cz_ * cz_;
+            const bool keepa = active & (ja < e) & (ja != i) & (d2a <= rl2f) & !(i_wall & (pa.id < wall_below));
+            const bool keepb = active & (jb < e) & (jb != i) & (d2b <= rl2f) & !(i_wall & (pb.id < wall_below));
+            const uint32_t bitsa = (uint32_t)(__ballot(keepa) >> (lane & 60u)) & 0xFu;
+            const uint32_t bitsb = (uint32_t)(__ballot(keepb) >> (lane & 60u)) & 0xFu;
+            const uint32_t below = (1u << q) - 1u;
+            const uint32_t ata = k + __popc(bitsa & below);
+            const uint32_t atb = k + __popc(bitsa) + __popc(bitsb & below);
+            if (keepa && ata < cap) row[ata] = ja;
+            if (keepb && atb < cap) row[atb] = jb;
+            k += __popc(bitsa) + __popc(bitsb);
+        }
+    };
+    /* per x-layer of cells: the cell-table entries of its 9 (3) cells are requested together,
+     * then the cells are walked; a cell is left out when even its nearest point is out of reach */
+    constexpr int NYZ = DIM == 3 ? 9 : 3;
     for (int dx = -1; dx <= 1; ++dx) {
         const int ax = cx + dx;
         if (ax < 0 || ax >= g.n[0]) continue;
         const double gx = dx < 0 ? fx : (dx > 0 ? 1.0 - fx : 0.0);
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int ay = cy + dy;
-            if (ay < 0 || ay >= g.n[1]) continue;
+        /* x_i - x_j = (u_i - dx*edge) - u_j for a candidate dx cells away */
+        const float bx = pi.u - (float)dx * edge;
+        uint32_t cb[NYZ], ce[NYZ], qb[NYZ], qe[NYZ];
+#pragma unroll
+        for (int t = 0; t < NYZ; ++t) {
+            const int dy = DIM == 3 ? t / 3 - 1 : t - 1, dz = DIM == 3 ? t % 3 - 1 : 0;
+            const int ay = cy + dy, az = cz + dz;
             const double gy = dy < 0 ? fy : (dy > 0 ? 1.0 - fy : 0.0);
-            for (int dz = (DIM == 3 ? -1 : 0); dz <= (DIM == 3 ? 1 : 0); ++dz) {
-                const int az = cz + dz;
-                if (DIM == 3 && (az < 0 || az >= g.n[2])) continue;
-                const double gz = dz < 0 ? fz : (dz > 0 ? 1.0 - fz : 0.0);
-                if (gx * gx + gy * gy + gz * gz > reach2) continue;
-                const uint32_t c = cell_key<DIM>(g, ax, ay, az);
-                /* own particles of the cell, then (slab runs) the neighbours' particles in it */
-                for (int part = 0; part < (hbeg ? 2 : 1); ++part) {
-                    const uint32_t b = part ? hbeg[c] : cbeg[c]; /* empty cell: b = 0xFFFFFFFF, e = 0 */
-                    const uint32_t e = part ? hend[c] : cend[c];
-                    for (uint32_t j0 = b; j0 < e; j0 += 4) {
-                        const uint32_t j = j0 + q;
-                        bool keep = false;
-                        if (active && j < e && j != i) {
-                            const Pos pj = pos[j];
-                            const double dx_ = xi - pj.x, dy_ = yi - pj.y;
-                            const double dz_ = DIM == 3 ? zi - pj.z : 0.0;
-                            keep = dist2_exact(dx_, dy_, dz_) <= rl2 && !(i_wall && pj.id < wall_below);
-                        }
-                        const uint32_t bits = (uint32_t)(__ballot(keep) >> (lane & 60u)) & 0xFu;
-                        const uint32_t at = k + __popc(bits & ((1u << q) - 1u));
-                        if (keep && at < cap) row[at] = j;
-                        k += __popc(bits);
-                    }
-                }
+            const double gz = dz < 0 ? fz : (dz > 0 ? 1.0 - fz : 0.0);
+            const bool take = ay >= 0 && ay < g.n[1] && (DIM != 3 || (az >= 0 && az < g.n[2])) &&
+                              !(gx * gx + gy * gy + gz * gz > reach2);
+            const uint32_t c = take ? cell_key<DIM>(g, ax, ay, az) : 0u; /* cell 0 always exists */
+            const uint32_t b0 = cbeg[c], e0 = cend[c];
+            cb[t] = take ? b0 : 0xFFFFFFFFu;
+            ce[t] = take ? e0 : 0u;
+            if (hbeg) {
+                const uint32_t b1 = hbeg[c], e1 = hend[c];
+                qb[t] = take ? b1 : 0xFFFFFFFFu;
+                qe[t] = take ? e1 : 0u;
             }
+        }
+#pragma unroll
+        for (int t = 0; t < NYZ; ++t) {
+            const int dy = DIM == 3 ? t / 3 - 1 : t - 1, dz = DIM == 3 ? t % 3 - 1 : 0;
+            const float by = pi.v - (float)dy * edge;
+            const float bz = DIM == 3 ? pi.w - (float)dz * edge : 0.0f;
+            /* own particles of the cell, then (slab runs) the neighbours' particles in it */
+            walk(cb[t], ce[t], bx, by, bz);
+            if (hbeg) walk(qb[t], qe[t], bx, by, bz);
         }
     }
     if (active && q == 0) {
