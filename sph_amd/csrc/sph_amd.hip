@@ -979,7 +979,7 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
                 c->use_cnt = c->cnt_in;
             }
             if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
-            hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS), dim3(SPH_BLOCK), 0, c->stream, c->part, part_n, PART_FIELDS,
+            hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS, PART_FIELDS), dim3(SPH_BLOCK), 0, c->stream, c->part, part_n, PART_FIELDS,
                                c->part2);
             hipLaunchKernelGGL(k_sweep_finalize, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->part2, k,
                                (last && !partial) ? 1 : (last ? 2 : 0), mode == 2 ? 0 : (inner ? 2 : 1));
@@ -1429,7 +1429,7 @@ int sph_forces(sph_ctx* c, int32_t which) {
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, c->stream, c->S);
     const uint32_t part_n = pairblocks(c->n);
     CHK(launch_pair<false>(c, c->rec[src], nullptr, out_state(c, which), 1, 0, 0, c->n, 0, part_n));
-    hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS), dim3(SPH_BLOCK), 0, c->stream, c->part, part_n, 1, c->part2);
+    hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS, 1), dim3(SPH_BLOCK), 0, c->stream, c->part, part_n, 1, c->part2);
     hipLaunchKernelGGL(k_forces_finalize, dim3(1), dim3(1), 0, c->stream, c->S, c->part2);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));

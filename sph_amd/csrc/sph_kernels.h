@@ -1046,29 +1046,29 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
 #define PART_FIELDS 5   /* max mu, max |f|^2, max move^2, sum move^2, pair count */
 #define PART_GROUPS 64
 
-/* First fold: group g reduces a fixed contiguous share of the workgroup partials, so the
- * summation order never depends on scheduling.  part2[field*PART_GROUPS + g]. */
+/* First fold: group g (blockIdx.x) reduces a fixed contiguous share of the workgroup partials of
+ * field blockIdx.y, in a fixed order (strided per thread, butterfly per wave, waves in turn), so
+ * the sums never depend on scheduling.  part2[field*PART_GROUPS + g]. */
 __global__ __launch_bounds__(SPH_BLOCK) void k_fold_parts(const double* __restrict__ part, uint32_t nb, int nfields,
                                                           double* __restrict__ part2) {
-    __shared__ double sh[SPH_BLOCK];
+    __shared__ double sh[SPH_BLOCK / 64];
+    const int f = blockIdx.y;
+    const bool is_sum = f >= 3;
     const uint32_t share = (nb + PART_GROUPS - 1) / PART_GROUPS;
     const uint32_t lo = blockIdx.x * share, hi = min(nb, lo + share);
-    for (int f = 0; f < nfields; ++f) {
-        const bool is_sum = f >= 3;
-        double v = 0.0;
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += SPH_BLOCK) {
-            const double x = part[(size_t)f * nb + i];
-            v = is_sum ? v + x : fmax(v, x);
-        }
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = SPH_BLOCK / 2; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o)
-                sh[threadIdx.x] = is_sum ? sh[threadIdx.x] + sh[threadIdx.x + o] : fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) part2[f * PART_GROUPS + blockIdx.x] = sh[0];
-        __syncthreads();
+    const double* const src = part + (size_t)f * nb;
+    double v = 0.0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += SPH_BLOCK) {
+        const double x = src[i];
+        v = is_sum ? v + x : fmax(v, x);
+    }
+    v = is_sum ? wave_sum(v) : wave_max(v);
+    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = sh[0];
+        for (int w = 1; w < SPH_BLOCK / 64; ++w) a = is_sum ? a + sh[w] : fmax(a, sh[w]);
+        part2[f * PART_GROUPS + blockIdx.x] = a;
     }
 }
 
