@@ -1696,9 +1696,11 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_level(DevParams P, Rec* __
         reinit_one<DIM>(P, rec, nbr, stride, cnt, id, pend, queue[q], lane,
                         [&](uint32_t j) { queue[atomicAdd(&ctl->tail, 1u)] = j; });
     /* the block that finishes last hands the next frontier to the next launch */
+    /* every lane's add to the queue tail has returned by now (its result was the lane's slot), and
+     * those adds and the ticket are device-scope atomics: the last ticket holder reads the final
+     * tail.  What the level stored (rho, queue entries) is for the next launch to read. */
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
         if (atomicAdd(&ctl->ticket, 1u) == gridDim.x - 1) {
             ctl->ticket = 0;
             ctl->begin = end;
