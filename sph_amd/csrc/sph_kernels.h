@@ -1582,6 +1582,10 @@ __device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__
                                            const uint32_t* __restrict__ id, uint32_t* __restrict__ pend, uint32_t i,
                                            uint32_t lane, Release release) {
     constexpr int N = DIM + 1;
+    /* this lane's first candidate is requested together with the particle's own data, and its
+     * record before the count is known (entries past the count are stale but index the arrays):
+     * one dependent trip fewer per level */
+    const uint32_t j_first = nbr[(size_t)i * stride + min(lane, stride - 1u)];
     const Rec ri = rec[i];
     const uint32_t me = id[i], c = cnt[i];
     /* Abar (WCXSPH3D.cpp:218-229) is symmetric: its upper triangle, accumulated per lane */
@@ -1613,9 +1617,9 @@ __device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__
         bool in;
         double e[N], W, m, rho;
     };
-    auto fetch = [&](uint32_t k) {
+    auto fetch_j = [&](uint32_t j) {
         Nb b;
-        b.j = nbr[(size_t)i * stride + k];
+        b.j = j;
         const Rec rj = rec[b.j];
         b.idj = id[b.j];
         const double d2 = dist2_exact(rj.xv[0][0] - ri.xv[0][0], rj.xv[1][0] - ri.xv[1][0],
@@ -1631,15 +1635,11 @@ __device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__
         b.rho = (double)rj.rho;
         return b;
     };
+    auto fetch = [&](uint32_t k) { return fetch_j(nbr[(size_t)i * stride + k]); };
     /* the first 64 candidates stay in registers for the second pass */
-    Nb first;
-    first.in = false;
-    first.j = 0;
-    first.idj = 0;
-    if (lane < c) {
-        first = fetch(lane);
-        if (first.in) add_A(first.e, first.W, first.m, first.rho);
-    }
+    Nb first = fetch_j(j_first);
+    first.in = first.in && lane < c;
+    if (first.in) add_A(first.e, first.W, first.m, first.rho);
     for (uint32_t k = lane + 64; k < c; k += 64) {
         const Nb b = fetch(k);
         if (b.in) add_A(b.e, b.W, b.m, b.rho);
