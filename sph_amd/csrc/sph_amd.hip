@@ -1537,7 +1537,7 @@ int sph_density_reinit(sph_ctx* c) {
         uint32_t done_before = 0;
         for (uint64_t round = 0;; ++round) {
             for (;;) { /* the local walk, until its queue runs dry */
-                for (int b = 0; b < batch; ++b) RI(k_reinit_level, dim3(grid), dim3(SPH_BLOCK), 0, c->stream);
+                for (int b = 0; b < batch; ++b) RI(k_reinit_level, dim3(grid), dim3(REINIT_LEVEL_THREADS), 0, c->stream);
                 c->reinit_launches += batch;
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));
@@ -1592,9 +1592,9 @@ int sph_density_reinit(sph_ctx* c) {
             return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
     } else {
     /* one launch per dependency level; the host looks at the queue every so often */
-    const int batch = 256, grid = 256; /* one wavefront per released particle, 1024 per pass of the grid */
+    const int batch = 256, grid = 256; /* one wavefront per released particle, 4096 per pass of the grid */
     for (uint64_t guard = 0;; ++guard) {
-        for (int b = 0; b < batch; ++b) RI(k_reinit_level, dim3(grid), dim3(SPH_BLOCK), 0, c->stream);
+        for (int b = 0; b < batch; ++b) RI(k_reinit_level, dim3(grid), dim3(REINIT_LEVEL_THREADS), 0, c->stream);
         c->reinit_launches += batch;
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));

@@ -1683,15 +1683,18 @@ __device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__
     }
 }
 
+#define REINIT_LEVEL_THREADS 1024 /* 256 workgroups of 16 waves: a frontier of 4096 particles in one pass */
 template <int DIM>
-__global__ __launch_bounds__(SPH_BLOCK) void k_reinit_level(DevParams P, Rec* __restrict__ rec,
+__global__ __launch_bounds__(REINIT_LEVEL_THREADS) void k_reinit_level(DevParams P, Rec* __restrict__ rec,
                                                             const uint32_t* __restrict__ nbr, uint32_t stride,
                                                             const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
                                                             uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
                                                             ReinitCtl* __restrict__ ctl) {
     const uint32_t begin = ctl->begin, end = ctl->end;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * SPH_BLOCK + threadIdx.x) >> 6, nwaves = gridDim.x * (SPH_BLOCK / 64);
+    /* consecutive queue entries go to different workgroups, so a short frontier is spread over
+     * the compute units instead of filling the first few */
+    const uint32_t wave = (threadIdx.x >> 6) * gridDim.x + blockIdx.x, nwaves = gridDim.x * (REINIT_LEVEL_THREADS / 64);
     for (uint32_t q = begin + wave; q < end; q += nwaves)
         reinit_one<DIM>(P, rec, nbr, stride, cnt, id, pend, queue[q], lane,
                         [&](uint32_t j) { queue[atomicAdd(&ctl->tail, 1u)] = j; });
