@@ -1424,18 +1424,28 @@ __device__ __forceinline__ bool fullpiv_solve_e0(double (&lu)[N][N], double (&be
         if (biggest > maxpivot) maxpivot = biggest;
         rowT[kk] = br;
         colT[kk] = bc;
+        /* the transpositions as selects over fixed places (a branch on the pivot's row or column
+         * would be merged into an indexed access, and the matrix would leave the registers) */
 #pragma unroll
-        for (int r = kk + 1; r < N; ++r)
-            if (r == br) {
+        for (int r = kk + 1; r < N; ++r) {
+            const bool sw = r == br;
 #pragma unroll
-                for (int c = 0; c < N; ++c) { const double t = lu[kk][c]; lu[kk][c] = lu[r][c]; lu[r][c] = t; }
+            for (int c = 0; c < N; ++c) {
+                const double a = lu[kk][c], b = lu[r][c];
+                lu[kk][c] = sw ? b : a;
+                lu[r][c] = sw ? a : b;
             }
+        }
 #pragma unroll
-        for (int c = kk + 1; c < N; ++c)
-            if (c == bc) {
+        for (int c = kk + 1; c < N; ++c) {
+            const bool sw = c == bc;
 #pragma unroll
-                for (int r = 0; r < N; ++r) { const double t = lu[r][kk]; lu[r][kk] = lu[r][c]; lu[r][c] = t; }
+            for (int r = 0; r < N; ++r) {
+                const double a = lu[r][kk], b = lu[r][c];
+                lu[r][kk] = sw ? b : a;
+                lu[r][c] = sw ? a : b;
             }
+        }
 #pragma unroll
         for (int r = kk + 1; r < N; ++r) lu[r][kk] /= lu[kk][kk];
 #pragma unroll
@@ -1455,8 +1465,12 @@ __device__ __forceinline__ bool fullpiv_solve_e0(double (&lu)[N][N], double (&be
 #pragma unroll
     for (int kk = 0; kk < N; ++kk) /* c = P*e0: the row transpositions in order */
 #pragma unroll
-        for (int r = kk + 1; r < N; ++r)
-            if (r == rowT[kk]) { const double t = c[kk]; c[kk] = c[r]; c[r] = t; }
+        for (int r = kk + 1; r < N; ++r) {
+            const bool sw = r == rowT[kk];
+            const double a = c[kk], b = c[r];
+            c[kk] = sw ? b : a;
+            c[r] = sw ? a : b;
+        }
 #pragma unroll
     for (int r = 0; r < N; ++r)
 #pragma unroll
@@ -1470,8 +1484,12 @@ __device__ __forceinline__ bool fullpiv_solve_e0(double (&lu)[N][N], double (&be
 #pragma unroll
     for (int kk = N - 1; kk >= 0; --kk) /* x = Q*c: the column transpositions undone */
 #pragma unroll
-        for (int r = kk + 1; r < N; ++r)
-            if (r == colT[kk]) { const double t = c[kk]; c[kk] = c[r]; c[r] = t; }
+        for (int r = kk + 1; r < N; ++r) {
+            const bool sw = r == colT[kk];
+            const double a = c[kk], b = c[r];
+            c[kk] = sw ? b : a;
+            c[r] = sw ? a : b;
+        }
 #pragma unroll
     for (int i = 0; i < N; ++i) beta[i] = c[i];
     return true;
