@@ -21,7 +21,8 @@ class Case(C.Structure):
     _fields_ = [("variant", C.c_int32), ("npart", C.c_int32 * 3), ("pstep", C.c_double),
                 ("box", C.c_double * 3), ("start", C.c_double * 3), ("dt0", C.c_double),
                 ("simtype", C.c_int32), ("reserved_", C.c_int32), ("drop_radius", C.c_double),
-                ("drop_centre", C.c_double * 3), ("drop_height", C.c_double), ("drop_v", C.c_double * 3)]
+                ("drop_centre", C.c_double * 3), ("drop_height", C.c_double), ("drop_v", C.c_double * 3),
+                ("rho0", C.c_double), ("Cs", C.c_double), ("alpha", C.c_double), ("gravity", C.c_double)]
 
 
 class Consts(C.Structure):
@@ -82,9 +83,12 @@ def default_case(variant):
     return c
 
 
-def make_case(variant, npart, pstep, box, start, dt0=0.0002, drop=None):
-    """drop: None or dict(simtype=1|2, radius, centre, height, v) -- the added droplet / jet."""
+def make_case(variant, npart, pstep, box, start, dt0=0.0002, drop=None, phys=None):
+    """drop: None or dict(simtype=1|2, radius, centre, height, v) -- the added droplet / jet.
+    phys: None or dict with any of rho0, Cs, alpha, gravity (the reference's constants otherwise)."""
     c = Case()
+    for k, v in (phys or {}).items():
+        setattr(c, k, float(v))
     if drop:
         c.simtype = int(drop["simtype"])
         c.drop_radius = float(drop["radius"])

@@ -144,7 +144,7 @@ int orc_derive(const orc_case* c, orc_consts* k) {
         const double finish = c->start[d] + c->pstep * c->npart[d] * 1.0;
         span[d] = finish - c->start[d];
     }
-    k->rho0 = 1000.0;
+    k->rho0 = c->rho0 > 0 ? c->rho0 : 1000.0;
     /* WCXSPH3D.cpp:52-53 / WCXSPH.cpp:49-50 / WCSPH.cpp:55 */
     double vol = span[0] * span[1];
     if (dim == 3) vol = vol * span[2];
@@ -157,7 +157,7 @@ int orc_derive(const orc_case* c, orc_consts* k) {
         visit_drop(c, dim, [&](const double*) { ++extra; });
         k->sim_pts += extra;
     }
-    k->Cs = 50;
+    k->Cs = c->Cs > 0 ? c->Cs : 50;
     k->gam = 7.0;
     k->B = k->rho0 * pow(k->Cs, 2) / k->gam; /* WCXSPH3D.cpp:56 */
     /* WCXSPH3D.cpp:59-63 / WCXSPH.cpp:56-57,120 */
@@ -173,13 +173,13 @@ int orc_derive(const orc_case* c, orc_consts* k) {
     /* WCXSPH3D.cpp:97 / WCXSPH.cpp:92 / WCSPH.cpp:96 */
     if (c->variant == ORC_WCSPH) k->search_radius = 4 * k->HSQ + 0.001 * k->H;
     else k->search_radius = 4 * k->HSQ;
-    k->alpha = 0.025; /* WCXSPH3D.cpp:142 */
+    k->alpha = c->alpha > 0 ? c->alpha : 0.025; /* WCXSPH3D.cpp:142 */
     k->eps = 0.2;     /* WCXSPH3D.cpp:143 */
     const float beta = 0.25;
     k->beta = beta;
     k->subits = 8;
     k->g_axis = dim - 1; /* f(1) in 2-D, f(2) in 3-D: WCXSPH.cpp:191, WCXSPH3D.cpp:195 */
-    k->g = -9.81;
+    k->g = c->gravity > 0 ? -c->gravity : -9.81;
     k->bound_parts = count_wall(c, dim);
     k->npts = k->bound_parts + k->sim_pts;
     return 0;

@@ -49,6 +49,9 @@ typedef struct orc_case {
     double  drop_centre[3];
     double  drop_height;
     double  drop_v[3];
+    /* The reference's compile-time constants, changeable the way a settings file would: 0 keeps
+     * the reference's value (rho0 1000, Cs 50, alpha 0.025, gravity 9.81 pointing down). */
+    double  rho0, Cs, alpha, gravity;
 } orc_case;
 
 /* Derived constants (WCXSPH3D.cpp:50-79,97 and the parallel 2-D lines). */

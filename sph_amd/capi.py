@@ -151,10 +151,13 @@ def default_case(program):
 SIMTYPE_BOX, SIMTYPE_DROPLET, SIMTYPE_JET = 0, 1, 2
 
 
-def make_case(program, npart, pstep, box, start, dt0=0.0002, drop=None):
+def make_case(program, npart, pstep, box, start, dt0=0.0002, drop=None, phys=None):
     """drop: None or dict(simtype=1|2, radius, centre, height, v) -- a droplet / jet next to the
-    reference's block (no counterpart in the reference)."""
+    reference's block (no counterpart in the reference).
+    phys: None or dict with any of rho0, Cs, alpha, gravity (the reference's constants otherwise)."""
     c = Case()
+    for k, v in (phys or {}).items():
+        setattr(c, k, float(v))
     if drop:
         c.simtype = int(drop["simtype"])
         c.drop_radius = float(drop["radius"])

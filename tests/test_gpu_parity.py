@@ -492,3 +492,29 @@ def test_a_particle_gone_nan_does_not_fault():
     others = np.delete(g, int(p.bound_parts) + 5, axis=1)
     assert np.isfinite(others[:, : int(p.bound_parts)]).all()
     sim.close()
+
+
+# ---- constants a settings file may change ---------------------------------------------------------
+# rho_ref, viscosity, gravity (Sample_Input.txt:8-11) and the speed of sound replace the reference's
+# compile-time constants (WCXSPH3D.cpp:54-56,142,195); the oracle takes the same overrides.
+
+PHYS = dict(rho0=850.0, Cs=40.0, alpha=0.08, gravity=3.7)
+
+
+@pytest.mark.parametrize("name", ["wcxsph3d_block", "wcxsph_fine", "wcsph_fine"])
+def test_changed_physical_constants(name):
+    spec = dict(CASES[name], phys=PHYS)
+    orc, sim = start(spec)
+    assert orc.k.rho0 == 850.0 and orc.k.g == -3.7
+    assert_state_close(sim.download(capi.STATE_N), orc.get_state(O.STATE_N), name + " Forces")
+    orc.step(10)
+    sc = sim.step(10)
+    assert_state_close(sim.download(capi.STATE_N), orc.get_state(O.STATE_N), name)
+    assert_scalars_close(sc, orc.scalars(), name)
+    go, gc = sim.neighbours(capi.STATE_NP1)
+    oo, occ = orc.neighbours(O.STATE_NP1)
+    assert np.array_equal(go, oo) and np.array_equal(gc, occ)
+    orc.density_reinit()
+    sim.density_reinit()
+    assert util.float_ulp_diff(sim.download(capi.STATE_NP1)["rho"], orc.get_state(O.STATE_NP1)["rho"]).max() <= 1
+    sim.close()

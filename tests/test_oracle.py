@@ -166,3 +166,24 @@ def test_oracle_reproduces_golden(name, variant):
     assert np.float32(sc["t"]) == gold["t"]
     offs, cols = orc.neighbours(O.STATE_NP1)
     assert np.array_equal(offs, gold["nbr_offsets"]) and np.array_equal(cols, gold["nbr_cols"])
+
+
+def test_changed_constants_follow_the_source_formulas():
+    # B = rho0 Cs^2 / gam (WCXSPH3D.cpp:56); f = g at t = 0 with the changed gravity; the first
+    # sweep's closed form with it (WCXSPH3D.cpp:271-277)
+    c = O.make_case(O.WCXSPH3D, (6, 5, 4), 0.1, (1.2, 1.0, 0.9), (0.15, 0.15, 0.15),
+                    phys=dict(rho0=850.0, Cs=40.0, alpha=0.08, gravity=3.7))
+    o = O.Oracle(c)
+    assert o.k.B == 850.0 * 40.0 ** 2 / 7.0 and o.k.alpha == 0.08 and o.k.g == -3.7
+    o.forces(O.STATE_N)
+    st = o.get_state(O.STATE_N)
+    fluid = slice(o.bound_parts, None)
+    assert np.all(st["rho"] == np.float32(850.0))
+    assert np.all(st["f"][fluid, 2] == -3.7) and np.all(st["f"][fluid, :2] == 0.0)
+    o.zero_boundary_f(O.STATE_N)
+    x0 = st["x"].copy()
+    o.step(1, 1)
+    s1 = o.get_state(O.STATE_NP1)
+    dt = 0.0002
+    assert np.allclose(s1["v"][fluid, 2], -3.7 * dt, rtol=1e-14, atol=0)
+    assert np.allclose(s1["x"][fluid, 2] - x0[fluid, 2], -0.5 * 3.7 * dt * dt, rtol=1e-9, atol=0)

@@ -29,7 +29,8 @@ def both_cases(spec):
         return O.default_case(prog), capi.default_case(prog)
     args = (spec["npart"], spec["pstep"], spec["box"], spec["start"], spec.get("dt0", 0.0002))
     drop = spec.get("drop")
-    return O.make_case(prog, *args, drop=drop), capi.make_case(prog, *args, drop=drop)
+    phys = spec.get("phys")
+    return O.make_case(prog, *args, drop=drop, phys=phys), capi.make_case(prog, *args, drop=drop, phys=phys)
 
 
 def drop_cases():
