@@ -1382,6 +1382,8 @@ struct ReinitCtl {
     uint32_t tail;       /* end of the queue */
     uint32_t ticket;     /* blocks of the running launch that have finished */
 };
+/* k_reinit_level adds to tail and ticket with one 8-byte atomic (tail is the low word) */
+static_assert(offsetof(ReinitCtl, tail) == 8 && offsetof(ReinitCtl, ticket) == 12, "tail and ticket form one aligned 8-byte word");
 
 /* W2Kernel (WCXSPH3D.cpp:121-128) */
 __device__ __forceinline__ double w2_kernel(const DevParams& P, double r) {
@@ -1708,25 +1710,44 @@ __global__ __launch_bounds__(REINIT_LEVEL_THREADS) void k_reinit_level(DevParams
                                                             const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
                                                             uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
                                                             ReinitCtl* __restrict__ ctl) {
+    /* The particles a workgroup sets free are collected in LDS and get their places in the queue
+     * with ONE add to the tail per workgroup: a thousand adds per level to that one word would
+     * queue up at the memory side, and the add leaves each wave's chain of dependent steps. */
+    constexpr uint32_t ROOM = 2048;
+    __shared__ uint32_t s_list[ROOM];
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
     const uint32_t begin = ctl->begin, end = ctl->end;
     const uint32_t lane = threadIdx.x & 63u;
     /* consecutive queue entries go to different workgroups, so a short frontier is spread over
      * the compute units instead of filling the first few */
     const uint32_t wave = (threadIdx.x >> 6) * gridDim.x + blockIdx.x, nwaves = gridDim.x * (REINIT_LEVEL_THREADS / 64);
     for (uint32_t q = begin + wave; q < end; q += nwaves)
-        reinit_one<DIM>(P, rec, nbr, stride, cnt, id, pend, queue[q], lane,
-                        [&](uint32_t j) { queue[atomicAdd(&ctl->tail, 1u)] = j; });
-    /* the block that finishes last hands the next frontier to the next launch */
-    /* every lane's add to the queue tail has returned by now (its result was the lane's slot), and
-     * those adds and the ticket are device-scope atomics: the last ticket holder reads the final
-     * tail.  What the level stored (rho, queue entries) is for the next launch to read. */
+        reinit_one<DIM>(P, rec, nbr, stride, cnt, id, pend, queue[q], lane, [&](uint32_t j) {
+            const uint32_t slot = atomicAdd(&s_n, 1u);
+            if (slot < ROOM) s_list[slot] = j;
+            else queue[(uint32_t)atomicAdd((unsigned long long*)&ctl->tail, 1ull)] = j; /* no room left: straight to the queue */
+        });
     __syncthreads();
+    const uint32_t mine = min(s_n, ROOM);
+    /* tail (low word) and ticket (high word) are one 8-byte word: a single add gives the workgroup
+     * its places in the queue and its ticket.  The workgroup that draws the last ticket was the
+     * last to add, so the tail it sees plus its own share is final: it hands the next frontier to
+     * the next launch.  What the level stored (rho, queue entries) is for that launch to read. */
+    __shared__ uint32_t s_last;
     if (threadIdx.x == 0) {
-        if (atomicAdd(&ctl->ticket, 1u) == gridDim.x - 1) {
-            ctl->ticket = 0;
-            ctl->begin = end;
-            ctl->end = __hip_atomic_load(&ctl->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const unsigned long long old =
+            atomicAdd((unsigned long long*)&ctl->tail, (1ull << 32) | (unsigned long long)mine);
+        s_base = (uint32_t)old;
+        s_last = (uint32_t)(old >> 32) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < mine; t += REINIT_LEVEL_THREADS) queue[s_base + t] = s_list[t];
+    if (threadIdx.x == 0 && s_last) {
+        ctl->ticket = 0;
+        ctl->begin = end;
+        ctl->end = s_base + mine;
     }
 }
 
