@@ -1762,23 +1762,28 @@ __global__ __launch_bounds__(REINIT_SINGLE_THREADS) void k_reinit_single(DevPara
                                                                          const uint32_t* __restrict__ id,
                                                                          uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
                                                                          ReinitCtl* __restrict__ ctl) {
-    __shared__ uint32_t s_end;
+    /* the queue's tail lives in LDS while the walk runs: handing out a place is an LDS atomic,
+     * not a trip to memory in every wave's chain of dependent steps */
+    __shared__ uint32_t s_tail;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = REINIT_SINGLE_THREADS / 64;
     uint32_t begin = 0, end = ctl->end;
+    if (threadIdx.x == 0) s_tail = end; /* k_reinit_start: end = tail */
+    __syncthreads();
     while (begin < end) { /* uniform: every thread holds the same begin and end */
         for (uint32_t q = begin + wave; q < end; q += nwaves)
             reinit_one<DIM>(P, rec, nbr, stride, cnt, id, pend, queue[q], lane,
-                            [&](uint32_t j) { queue[atomicAdd(&ctl->tail, 1u)] = j; });
+                            [&](uint32_t j) { queue[atomicAdd(&s_tail, 1u)] = j; });
         __threadfence_block();
         __syncthreads();
-        if (threadIdx.x == 0) s_end = __hip_atomic_load(&ctl->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
+        const uint32_t now = s_tail;
+        __syncthreads(); /* everyone has read the tail before the next level adds to it */
         begin = end;
-        end = s_end;
+        end = now;
     }
     if (threadIdx.x == 0) {
         ctl->begin = begin;
         ctl->end = begin;
+        ctl->tail = s_tail;
     }
 }
 
