@@ -1583,7 +1583,7 @@ int sph_density_reinit(sph_ctx* c) {
             if (v[1] == 0.0) return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
             done_before = done_now;
         }
-    } else if (n <= 16384) { /* a small case is walked by one workgroup, level after level */
+    } else if (n <= REINIT_SINGLE_MAX) { /* a small case is walked by one workgroup, level after level */
         RI(k_reinit_single, dim3(1), dim3(REINIT_SINGLE_THREADS), 0, c->stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));

@@ -1755,6 +1755,7 @@ __global__ __launch_bounds__(REINIT_LEVEL_THREADS) void k_reinit_level(DevParams
  * a launch (all waves share the compute unit's cache, so a level sees the previous level's
  * stores).  A level with few particles then costs a barrier, not a kernel launch. */
 #define REINIT_SINGLE_THREADS 1024
+#define REINIT_SINGLE_MAX 12288 /* particles whose counters fit the workgroup's LDS */
 template <int DIM>
 __global__ __launch_bounds__(REINIT_SINGLE_THREADS) void k_reinit_single(DevParams P, Rec* __restrict__ rec,
                                                                          const uint32_t* __restrict__ nbr, uint32_t stride,
@@ -1765,13 +1766,16 @@ __global__ __launch_bounds__(REINIT_SINGLE_THREADS) void k_reinit_single(DevPara
     /* the queue's tail lives in LDS while the walk runs: handing out a place is an LDS atomic,
      * not a trip to memory in every wave's chain of dependent steps */
     __shared__ uint32_t s_tail;
+    /* and so do the counts of unfinished smaller-index neighbours */
+    __shared__ uint32_t s_pend[REINIT_SINGLE_MAX];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = REINIT_SINGLE_THREADS / 64;
     uint32_t begin = 0, end = ctl->end;
     if (threadIdx.x == 0) s_tail = end; /* k_reinit_start: end = tail */
+    for (uint32_t t = threadIdx.x; t < P.n; t += REINIT_SINGLE_THREADS) s_pend[t] = pend[t];
     __syncthreads();
     while (begin < end) { /* uniform: every thread holds the same begin and end */
         for (uint32_t q = begin + wave; q < end; q += nwaves)
-            reinit_one<DIM>(P, rec, nbr, stride, cnt, id, pend, queue[q], lane,
+            reinit_one<DIM>(P, rec, nbr, stride, cnt, id, s_pend, queue[q], lane,
                             [&](uint32_t j) { queue[atomicAdd(&s_tail, 1u)] = j; });
         __threadfence_block();
         __syncthreads();

@@ -358,7 +358,7 @@ def test_frames_with_density_reinit(name):
     dict(program=2, npart=(24, 20, 16), pstep=0.1, box=(3.0, 2.4, 2.2), start=(0.15, 0.15, 0.15)),
 ], ids=["2d_20k", "3d_22k"])
 def test_density_reinit_beyond_the_one_workgroup_size(spec):
-    # cases of up to 16384 particles are walked by one workgroup; larger ones by one launch per level
+    # cases of up to 12288 particles are walked by one workgroup; larger ones by one launch per level
     orc, sim = start(spec)
     assert orc.npts > 16384
     orc.step(4)
