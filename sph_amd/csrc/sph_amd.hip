@@ -1164,9 +1164,6 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     d.sqrtBgam = std::sqrt(d.Bgam);
     d.invH = 1.0 / p->H;
     d.gconst = 5.0 * (1.0 / p->HSQ) * p->correc;
-    d.vk1 = 0.5 * p->alpha * d.sqrtBgam;
-    d.mhalf_invH = -0.5 * d.invH;
-    d.kconst = p->eps * p->correc;
 
     const size_t n = c->cap;
     for (int q = 0; q < 4; ++q)

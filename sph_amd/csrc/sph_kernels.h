@@ -703,14 +703,10 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
     const double xi0 = ri.xv[0][0], xi1 = ri.xv[1][0], xi2 = ri.xv[2][0];
     const double vi0 = ri.xv[0][1], vi1 = ri.xv[1][1], vi2 = ri.xv[2][1];
     const double rho_i = (double)ri.rho;
-    /* alpha * cbar = alpha/2 (c_i + c_j) with c = sqrt(B*gam/rho) (WCXSPH3D.cpp:172-173), formed
-     * per pair as one fused multiply-add: vk1 * rho_j^(-1/2) + vk0; WCSPH carries the sign of
-     * its viscous term here */
-    const double vk1 = XSPH ? P.vk1 : -P.vk1;
-    const double vk0 = vk1 * fast_rsq(rho_i);
-    const double mhalf_invH = P.mhalf_invH;
+    const double sqrtBgam = P.sqrtBgam;
+    const double c_i = sqrtBgam * fast_rsq(rho_i); /* sqrt(B*gam/rho), WCXSPH3D.cpp:172 */
+    const double invH = P.invH;
     const double gconst = P.gconst;
-    const double kconst = P.kconst; /* XSPH: eps * W carries both constants */
 
     /* The candidate row of particle i: entry e at nbr[i*cap + e].  Every fourth round each
      * lane fetches 16 bytes of it: lane q holds the four candidates of round 4u+q. */
@@ -824,15 +820,16 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
             const double Vx = rj.xv[0][1] - vi0, Vy = rj.xv[1][1] - vi1;
             const double Vz = DIM == 3 ? rj.xv[2][1] - vi2 : 0.0;
             const double r = fast_sqrt(d2);
-            /* t1 = 1 - q/2 with q = r/H.  W2Kernel / W2GradK vanish for q >= 2
-             * (WCXSPH3D.cpp:124,133): the clamp makes t1 an exact zero there.  2q + 1 = 5 - 4 t1. */
-            const double t1 = fmax(fma(r, mhalf_invH, 1.0), 0.0);
+            const double qq = r * invH;
+            /* W2Kernel / W2GradK vanish for q >= 2 (WCXSPH3D.cpp:124,133): the clamp makes the
+             * factor (1 - q/2) an exact zero there */
+            const double t1 = fmax(1.0 - 0.5 * qq, 0.0);
             const double t2 = t1 * t1;
             const double gs = gconst * (t2 * t1);
-            const double eKern = XSPH ? (t2 * t2) * fma(-4.0, t1, 5.0) * kconst : 0.0; /* eps * W */
+            const double Kern = XSPH ? (t2 * t2) * (2.0 * qq + 1.0) * P.correc : 0.0;
             const double gx = Rx * gs, gy = Ry * gs, gz = Rz * gs;
             const double rho_j = (double)rj.rho;
-            const double acbar = fma(vk1, fast_rsq(rho_j), vk0);
+            const double cbar = 0.5 * (c_i + sqrtBgam * fast_rsq(rho_j));
             double vdotr = Vx * Rx + Vy * Ry;
             if (DIM == 3) vdotr += Vz * Rz;
             const double rhoij = 0.5 * (double)(ri.rho + rj.rho); /* float add, as the reference */
@@ -846,19 +843,19 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
             if (XSPH) {
                 /* viscosity only for approaching pairs (WCXSPH3D.cpp:175-178): mu has the sign
                  * of vdotr, and a zero factor gives the same zero */
-                const double pifac = acbar * fmin(muij, 0.0) * inv_rho;
+                const double pifac = P.alpha * cbar * fmin(muij, 0.0) * inv_rho;
                 const double mj = (double)rj.m;
                 const double sc = mj * (pifac - ri.prr - rj.prr);
                 acc0 += gx * sc;
                 acc1 += gy * sc;
                 if (DIM == 3) acc2 += gz * sc;
-                const double xs = (mj * inv_rho) * eKern;
+                const double xs = P.eps * (mj * inv_rho) * Kern;
                 Vs0 += xs * Vx;
                 Vs1 += xs * Vy;
                 if (DIM == 3) Vs2 += xs * Vz;
                 rr -= mj * vg;
             } else {
-                const double pifac = acbar * fmin(muij, 0.0) * inv_rho;
+                const double pifac = -P.alpha * cbar * fmin(muij, 0.0) * inv_rho;
                 const double sc = pifac + ri.prr + rj.prr;
                 acc0 -= gx * sc;
                 acc1 -= gy * sc;

@@ -32,9 +32,6 @@ struct DevParams {
     double   sqrtBgam;  /* sqrt(B*gam) */
     double   invH;      /* 1/H */
     double   gconst;    /* 5*(1/HSQ)*correc: the gradient's constant factor (WCXSPH3D.cpp:135) */
-    double   vk1;       /* alpha/2 * sqrt(B*gam): alpha*cbar = vk1 * (rho_i^-1/2 + rho_j^-1/2) */
-    double   mhalf_invH; /* -1/(2H): 1 - q/2 = 1 + r * mhalf_invH */
-    double   kconst;    /* eps * correc */
 };
 
 /* Uniform grid over the particles' bounding box. Cell edge >= candidate radius. */
