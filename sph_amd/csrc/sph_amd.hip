@@ -1513,10 +1513,10 @@ int sph_density_reinit(sph_ctx* c) {
     } while (0)
     uint32_t* touches = c->dist ? c->flags : nullptr;
     if (c->dim == 3)
-        hipLaunchKernelGGL(k_reinit_count<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k, c->cnt,
+        hipLaunchKernelGGL(k_reinit_count<3>, dim3((n + SPH_BLOCK / 4 - 1) / (SPH_BLOCK / 4)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k, c->cnt,
                            ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches);
     else
-        hipLaunchKernelGGL(k_reinit_count<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k, c->cnt,
+        hipLaunchKernelGGL(k_reinit_count<2>, dim3((n + SPH_BLOCK / 4 - 1) / (SPH_BLOCK / 4)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k, c->cnt,
                            ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches);
     hipLaunchKernelGGL(k_reinit_start, dim3(1), dim3(1), 0, c->stream, c->ri_ctl);
     HIPCHK(hipGetLastError());

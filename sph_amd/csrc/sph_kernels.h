@@ -1508,12 +1508,14 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_count(DevParams P, const R
                                                             const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
                                                             uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
                                                             ReinitCtl* __restrict__ ctl, uint32_t* __restrict__ touches) {
-    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
-    if (i >= P.n) return;
+    /* four lanes per particle, each taking every fourth candidate */
+    const uint32_t i_raw = blockIdx.x * (SPH_BLOCK / 4) + (threadIdx.x >> 2), q = threadIdx.x & 3u;
+    const bool active = i_raw < P.n;
+    const uint32_t i = active ? i_raw : P.n - 1u;
     const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
-    const uint32_t me = id[i], c = cnt[i];
+    const uint32_t me = id[i], c = active ? cnt[i] : 0u;
     uint32_t lower = 0, far = 0;
-    for (uint32_t k = 0; k < c; ++k) {
+    for (uint32_t k = q; k < c; k += 4) {
         const uint32_t j = nbr[(size_t)i * stride + k];
         const double d2 = dist2_exact(rec[j].xv[0][0] - xi, rec[j].xv[1][0] - yi, DIM == 3 ? rec[j].xv[2][0] - zi : 0.0);
         if (d2 < P.R2) {
@@ -1521,6 +1523,11 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_count(DevParams P, const R
             if (j >= P.n) far = 1;
         }
     }
+    lower += (uint32_t)quad_perm_i<QP_XOR1>((int)lower);
+    lower += (uint32_t)quad_perm_i<QP_XOR2>((int)lower);
+    far |= (uint32_t)quad_perm_i<QP_XOR1>((int)far);
+    far |= (uint32_t)quad_perm_i<QP_XOR2>((int)far);
+    if (!active || q != 0) return;
     pend[i] = lower;
     if (touches) touches[i] = far;
     if (lower == 0) queue[atomicAdd(&ctl->tail, 1u)] = i;
