@@ -21,7 +21,7 @@ PROGRAM_WCSPH, PROGRAM_WCXSPH, PROGRAM_WCXSPH3D = 0, 1, 2
 # every symbol include/sph_amd.h declares
 SYMBOLS = (
     "sph_create", "sph_destroy", "sph_last_error", "sph_upload", "sph_download", "sph_forces",
-    "sph_zero_boundary_forces", "sph_step", "sph_sweeps", "sph_get_scalars", "sph_set_dt",
+    "sph_zero_boundary_forces", "sph_step", "sph_step_noalloc", "sph_sweeps", "sph_get_scalars", "sph_set_dt",
     "sph_density_reinit", "sph_neighbours", "sph_profile_enable", "sph_profile_read",
     "sph_case_default", "sph_case_params", "sph_case_init",
     "sph_set_transport", "sph_upload_global_ids", "sph_rccl_unique_id", "sph_use_rccl",
@@ -105,6 +105,7 @@ def lib():
     L.sph_zero_boundary_forces.argtypes = [vp, C.c_int32]
     L.sph_step.argtypes = [vp, C.c_int32, C.POINTER(Scalars)]
     L.sph_sweeps.argtypes = [vp, C.c_int32, C.POINTER(Scalars)]
+    L.sph_step_noalloc.argtypes = [vp, C.c_int32, C.POINTER(Scalars)]
     L.sph_get_scalars.argtypes = [vp, C.POINTER(Scalars)]
     L.sph_set_dt.argtypes = [vp, C.c_double]
     L.sph_density_reinit.argtypes = [vp]
@@ -345,6 +346,12 @@ class Sim:
     def step(self, nsteps=1):
         s = Scalars()
         self._chk(lib().sph_step(self._h, nsteps, C.byref(s)), "sph_step")
+        return s.as_dict()
+
+    def step_noalloc(self, nsteps=1):
+        """sph_step through the entry point that allocates nothing."""
+        s = Scalars()
+        self._chk(lib().sph_step_noalloc(self._h, nsteps, C.byref(s)), "sph_step_noalloc")
         return s.as_dict()
 
     def sweeps(self, nsweeps):

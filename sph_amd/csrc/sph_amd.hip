@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -95,6 +96,12 @@ struct sph_ctx {
     DevScalars* S_host = nullptr; /* pinned */
     double* part = nullptr;  /* per-workgroup partials of the pair kernel */
     double* part2 = nullptr; /* their first fold */
+    /* where the launches of the call under way leave their partials: the two buffers above, or
+     * this device's copy of the file-scope scratch array (sph_step_noalloc) */
+    double* part_use = nullptr;
+    double* part2_use = nullptr;
+    double* scratch = nullptr; /* device address of this device's scratch array */
+    bool no_alloc = false;     /* the call under way may not allocate or free device memory */
     double* bbox_part = nullptr;
     double* bbox_host = nullptr; /* pinned */
     uint32_t* need_host = nullptr; /* pinned, 8 words */
@@ -148,6 +155,31 @@ namespace {
 
 constexpr int BBOX_BLOCKS = 1024;
 
+/* Scratch of sph_step_noalloc: the pair kernel's per-workgroup partials (PART_FIELDS per
+ * workgroup) and their first fold, for cases of up to SPH_NOALLOC_MAX_PARTICLES particles.
+ * One copy per GPU, held until the process ends.  In host code the array's name is only a
+ * handle for hipGetSymbolAddress: the address kept per device below is what the launches get. */
+constexpr uint32_t NOALLOC_PART_SLOTS = (SPH_NOALLOC_MAX_PARTICLES + PAIR_PARTICLES - 1) / PAIR_PARTICLES + 8 + 24;
+constexpr size_t NOALLOC_SCRATCH_DOUBLES = (size_t)PART_FIELDS * NOALLOC_PART_SLOTS + (size_t)PART_FIELDS * PART_GROUPS;
+static __device__ __align__(256) double g_noalloc_scratch[NOALLOC_SCRATCH_DOUBLES];
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+double* g_scratch_ptr[MAX_DEVICES] = {};
+
+/* Device address of the current device's copy of the scratch array (looked up once per device). */
+hipError_t scratch_of_current_device(int device, double** out) {
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        double* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_noalloc_scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 #define HIPCHK(call)                                                                          \
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \
@@ -169,15 +201,24 @@ constexpr int BBOX_BLOCKS = 1024;
 inline uint32_t nblk(uint32_t n) { return std::max(1u, (n + SPH_BLOCK - 1) / SPH_BLOCK); }
 inline uint32_t pairblocks(uint32_t count) { return ((count + PAIR_PARTICLES - 1) / PAIR_PARTICLES + 7u) & ~7u; }
 
-template <typename T>
-int dalloc(sph_ctx* c, T** p, size_t count) {
-    HIPCHK(hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
-    return SPH_OK;
-}
-
 int fail(sph_ctx* c, int code, const char* msg) {
     c->err = msg;
     return code;
+}
+
+template <typename T>
+int dalloc(sph_ctx* c, T** p, size_t count) {
+    if (c->no_alloc) return fail(c, SPH_ENOMEM, "this call may not allocate device memory and a buffer has to grow: make the same call through sph_step once");
+    HIPCHK(hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
+    return SPH_OK;
+}
+/* frees *p unless the call under way may not (the dalloc that follows then reports it) */
+template <typename T>
+int dfree(sph_ctx* c, T** p) {
+    if (c->no_alloc || !*p) return SPH_OK;
+    HIPCHK(hipFree(*p));
+    *p = nullptr;
+    return SPH_OK;
 }
 
 /* index helpers for the n-state component arrays */
@@ -194,8 +235,7 @@ inline const uint32_t* wall_ids(const sph_ctx* c) { return c->dist ? c->gid : c-
 int exclusive_scan(sph_ctx* c, const uint32_t* in, uint32_t* out, uint32_t n) {
     const uint32_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb > c->bsum_cap) {
-        if (c->bsum) HIPCHK(hipFree(c->bsum));
-        c->bsum = nullptr;
+        CHK(dfree(c, &c->bsum));
         CHK(dalloc(c, &c->bsum, (size_t)nb * 2));
         c->bsum_cap = (size_t)nb * 2;
     }
@@ -214,8 +254,7 @@ int radix_sort(sph_ctx* c, uint32_t*& keys, uint32_t*& keys_alt, uint32_t*& perm
     const uint32_t nb = (m + RS_TILE - 1) / RS_TILE;
     const size_t hsz = (size_t)256 * nb;
     if (hsz > c->hist_cap) {
-        if (c->hist) HIPCHK(hipFree(c->hist));
-        c->hist = nullptr;
+        CHK(dfree(c, &c->hist));
         CHK(dalloc(c, &c->hist, hsz));
         c->hist_cap = hsz;
     }
@@ -267,8 +306,7 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
         if (need <= c->cap_k) return SPH_OK;
         /* some particle has more candidates than the lists hold: grow and build again */
         const uint32_t newcap = (need + need / 8 + 7u) & ~3u;
-        HIPCHK(hipFree(c->nbr));
-        c->nbr = nullptr;
+        CHK(dfree(c, &c->nbr));
         CHK(dalloc(c, &c->nbr, (size_t)newcap * c->own_cap));
         HIPCHK(hipMemsetAsync(c->nbr, 0, sizeof(uint32_t) * (size_t)newcap * c->own_cap, c->stream));
         c->cap_k = newcap;
@@ -507,7 +545,7 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     const int dim = c->dim;
     if (c->dist && !c->have_tr) return fail(c, SPH_ESTATE, "no transport installed (sph_set_transport / sph_use_rccl)");
     EventPair* ev = nullptr;
-    if (c->profile) {
+    if (c->profile && !(c->no_alloc && c->rb_used == c->rb_pool.size())) {
         if (c->rb_used == c->rb_pool.size()) {
             EventPair e;
             HIPCHK(hipEventCreate(&e.a));
@@ -518,6 +556,7 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
         HIPCHK(hipEventRecord(ev->a, c->stream));
     }
     c->n_halo = 0; /* the neighbours' particles are fetched afresh below */
+    c->list_valid = false; /* until the new lists stand: a rebuild that fails half-way leaves none */
     uint32_t m_sort = n;
     const uint32_t* drop = nullptr;
     bool renumber = false;
@@ -821,7 +860,7 @@ int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out
     const bool wide = (uint64_t)c->cap * sizeof(Rec) >= (1ull << 32);
 #define LP(D, X, W)                                                                                                   \
     hipLaunchKernelGGL((k_pair<D, X, FUSED, FILTER, W>), g, b, 0, c->stream, c->dp, rin, walk, c->cap_k, walk_cnt, o, \
-                       store_out, zero_wall, ns, wall_ids(c), rout, c->pp, c->S, c->part, first, count,               \
+                       store_out, zero_wall, ns, wall_ids(c), rout, c->pp, c->S, c->part_use, first, count,           \
                        part_base, part_n, c->nbr_in, c->cnt_in, c->r_in2)
     if (c->dim == 3) { if (wide) LP(3, true, true); else LP(3, true, false); }
     else if (c->xsph) { if (wide) LP(2, true, true); else LP(2, true, false); }
@@ -940,8 +979,7 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
         if (inner) {
             /* room for the step's working lists, which the first sweep draws from the candidates */
             if (!c->nbr_in || c->nbr_in_cap_k != c->cap_k) {
-                if (c->nbr_in) HIPCHK(hipFree(c->nbr_in));
-                c->nbr_in = nullptr;
+                CHK(dfree(c, &c->nbr_in));
                 CHK(dalloc(c, &c->nbr_in, (size_t)c->cap_k * c->own_cap));
                 HIPCHK(hipMemsetAsync(c->nbr_in, 0, sizeof(uint32_t) * (size_t)c->cap_k * c->own_cap, c->stream));
                 c->nbr_in_cap_k = c->cap_k;
@@ -962,7 +1000,7 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             while (nxt == cur || nxt == c->b0) ++nxt;
             const bool last = k == nsweeps - 1;
             EventPair* ev = nullptr;
-            if (c->profile) {
+            if (c->profile && !(c->no_alloc && c->ev_used == c->ev_pool.size())) {
                 if (c->ev_used == c->ev_pool.size()) {
                     EventPair e;
                     HIPCHK(hipEventCreate(&e.a));
@@ -979,9 +1017,9 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
                 c->use_cnt = c->cnt_in;
             }
             if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
-            hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS, PART_FIELDS), dim3(SPH_BLOCK), 0, c->stream, c->part, part_n, PART_FIELDS,
-                               c->part2);
-            hipLaunchKernelGGL(k_sweep_finalize, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->part2, k,
+            hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS, PART_FIELDS), dim3(SPH_BLOCK), 0, c->stream, c->part_use, part_n, PART_FIELDS,
+                               c->part2_use);
+            hipLaunchKernelGGL(k_sweep_finalize, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->part2_use, k,
                                (last && !partial) ? 1 : (last ? 2 : 0), mode == 2 ? 0 : (inner ? 2 : 1));
             cur = nxt;
         }
@@ -1220,6 +1258,15 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     HIPCHK(hipHostMalloc((void**)&c->need_host, 8 * sizeof(uint32_t)));
     CHK(dalloc(c, &c->part, (size_t)PART_FIELDS * c->npairblocks));
     CHK(dalloc(c, &c->part2, (size_t)PART_FIELDS * PART_GROUPS));
+    c->part_use = c->part;
+    c->part2_use = c->part2;
+    HIPCHK(scratch_of_current_device(c->device, &c->scratch));
+    /* the sort's histogram and the scans' block sums at their largest, so that a list rebuild
+     * never allocates */
+    c->hist_cap = (size_t)256 * ((n + RS_TILE - 1) / RS_TILE);
+    CHK(dalloc(c, &c->hist, c->hist_cap));
+    c->bsum_cap = 2 * std::max((c->hist_cap + SCAN_TILE - 1) / SCAN_TILE, (n + SCAN_TILE - 1) / SCAN_TILE);
+    CHK(dalloc(c, &c->bsum, c->bsum_cap));
     CHK(dalloc(c, &c->bbox_part, (size_t)6 * BBOX_BLOCKS));
     HIPCHK(hipMalloc(&c->tmp, n * 8));
     if (c->dist) {
@@ -1426,8 +1473,8 @@ int sph_forces(sph_ctx* c, int32_t which) {
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, c->stream, c->S);
     const uint32_t part_n = pairblocks(c->n);
     CHK(launch_pair<false>(c, c->rec[src], nullptr, out_state(c, which), 1, 0, 0, c->n, 0, part_n));
-    hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS, 1), dim3(SPH_BLOCK), 0, c->stream, c->part, part_n, 1, c->part2);
-    hipLaunchKernelGGL(k_forces_finalize, dim3(1), dim3(1), 0, c->stream, c->S, c->part2);
+    hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS, 1), dim3(SPH_BLOCK), 0, c->stream, c->part_use, part_n, 1, c->part2_use);
+    hipLaunchKernelGGL(k_forces_finalize, dim3(1), dim3(1), 0, c->stream, c->S, c->part2_use);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->dist) {
@@ -1458,6 +1505,29 @@ int sph_step(sph_ctx* c, int32_t nsteps, sph_scalars* out) {
     HIPCHK(hipSetDevice(c->device));
     for (int s = 0; s < nsteps; ++s) CHK(one_step(c, 0, false));
     if (nsteps == 0) CHK(read_scalars(c));
+    fill_scalars(c, out);
+    return SPH_OK;
+}
+
+int sph_step_noalloc(sph_ctx* c, int32_t nsteps, sph_scalars* out) {
+    if (!c || nsteps < 0) return SPH_EINVAL;
+    if (!c->uploaded_n || !c->uploaded_np1) return fail(c, SPH_ESTATE, "both states must be uploaded before stepping");
+    if (c->dist) return fail(c, SPH_EINVAL, "sph_step_noalloc serves single-domain contexts only");
+    if (c->cap > SPH_NOALLOC_MAX_PARTICLES || (size_t)c->npairblocks > NOALLOC_PART_SLOTS)
+        return fail(c, SPH_EINVAL, "sph_step_noalloc: more particles than the fixed scratch array serves (SPH_NOALLOC_MAX_PARTICLES)");
+    HIPCHK(hipSetDevice(c->device));
+    /* the pair kernel's partials and their fold go to this device's scratch array; each sweep
+     * overwrites the slots it reads back, so nothing has to be cleared between calls */
+    c->part_use = c->scratch;
+    c->part2_use = c->scratch + (size_t)PART_FIELDS * NOALLOC_PART_SLOTS;
+    c->no_alloc = true;
+    int rc = SPH_OK;
+    for (int s = 0; s < nsteps && rc == SPH_OK; ++s) rc = one_step(c, 0, false);
+    if (rc == SPH_OK && nsteps == 0) rc = read_scalars(c);
+    c->no_alloc = false;
+    c->part_use = c->part;
+    c->part2_use = c->part2;
+    if (rc != SPH_OK) return rc;
     fill_scalars(c, out);
     return SPH_OK;
 }
