@@ -1,13 +1,20 @@
 """Headline benchmark: particle-steps/s of the 3-D WCXSPH dam break.
 
 One "step" is one full Newmark-beta call of the reference (WCXSPH3D.cpp:251-303): eight
-sweeps, each a neighbour search + Forces + update.  Inputs are resident in HBM before the
-timed region.  Prints ONE JSON line (rank 0).
+sweeps, each a fixed-radius neighbour search + Forces + update.  The reference rebuilds its
+search index before every sweep (WCXSPH3D.cpp:278); here candidate lists are rebuilt when the
+particles have travelled far enough to need it, which never happens while the column is still
+at rest.  The headline is therefore measured in DEVELOPED flow: the case is first advanced
+`--preroll` steps (untimed set-up of the workload, like filling the arrays), then W warm-up
+steps, then exactly K timed steps with list rebuilds among them.  The rate of the resting
+lattice (no rebuilds) is reported beside it as `config.at_rest`.  Inputs are resident in HBM
+before any timed region.  Prints ONE JSON line (rank 0).
 
   python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... [--scaling strong]
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -17,17 +24,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 # MI355X peaks used for the roofline fractions
 HBM_PEAK_GBS = 8000.0      # HBM3E spec
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector spec
-# Algorithmic traffic of the fused pair+update kernel per particle and sweep, 3-D, reference
-# precisions: pair stage 112 B (read x,v,rho,p,m 60 B; write f,V,Rrho 52 B) + integrate/EOS
-# stage 212 B.  Algorithmic flops: 80 per pair inside the radius (self included).
+# Algorithmic traffic per particle, 3-D, reference precisions.  Fused pair+update kernel, per
+# sweep: pair stage 112 B (read x,v,rho,p,m 60 B; write f,V,Rrho 52 B) + integrate/EOS stage
+# 212 B.  Neighbour build, per rebuild: read x 24 B, key+index 8 B, four radix passes of 16 B,
+# cell table 8 B = 104 B.  Algorithmic flops: 80 per pair inside the radius (self included).
 B_ALG_PAIR = 112.0
 B_ALG_UPDATE = 212.0
+B_ALG_REBUILD = 104.0
 FLOP_PER_PAIR = 80.0
+
+C3 = (640, 320, 48)
+C4 = (2048, 1024, 48)
 
 
 def dam_break_3d(nx, ny, nz):
@@ -40,10 +50,18 @@ def dam_break_3d(nx, ny, nz):
     return capi.make_case(capi.PROGRAM_WCXSPH3D, (nx, ny, nz), pstep, box, start)
 
 
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in ("sph_kernels.h", "sph_types.h"):
+        with open(os.path.join(ROOT, "sph_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(fluid, n):
     """HBM bytes per launch of the pair kernel from the committed counter run of this same
-    workload (rocprofv3 cannot run inside this process): FETCH_SIZE with its gfx950 correction
-    + WRITE_SIZE.  None when no counter run matches the workload."""
+    workload and of THIS kernel source (rocprofv3 cannot run inside this process): FETCH_SIZE
+    with its gfx950 correction + WRITE_SIZE.  None when no counter run matches."""
     try:
         with open(os.path.join(ROOT, "profiles", "pair_traffic.json")) as fh:
             t = json.load(fh)
@@ -51,15 +69,26 @@ def measured_traffic(fluid, n):
         return None
     if list(t["workload"]["fluid"]) != list(fluid) or t["particles"] != n:
         return None
+    if t.get("kernel_source_sha256_16") != kernel_source_hash():
+        return None
     reads = t["fetch_size_kib"] * 1024.0 + 0.5 * t["streamed_read_bytes_per_particle"] * n
     return reads + t["write_size_kib"] * 1024.0
 
 
 def cpu_baseline(sample=(64, 48, 32), steps=4):
-    """The oracle (a port: the reference itself needs Eigen+nanoflann) on one host core, on
-    a reduced block of the same case."""
+    """The oracle (a port: the reference itself needs Eigen+nanoflann) on one host core: the
+    2-D WCXSPH program as shipped for 20 steps, and a reduced block of the benchmark's 3-D
+    case.  `value` is the 3-D figure.  (A 1 M-particle block would take ~80 s of CPU for five
+    steps; the leg is held to ~15 s so that the default run finishes in about a minute.)"""
     from oracle import oracle as O
-    from sph_amd import capi
+    orc = O.Oracle(O.default_case(O.WCXSPH))
+    orc.forces(O.STATE_N)
+    orc.zero_boundary_f(O.STATE_N)
+    t0 = time.perf_counter()
+    orc.step(20)
+    dt1 = time.perf_counter() - t0
+    n1 = orc.npts
+    orc.close()
     pc = dam_break_3d(*sample)
     oc = O.make_case(O.WCXSPH3D, tuple(pc.npart), pc.pstep, tuple(pc.box), tuple(pc.start))
     orc = O.Oracle(oc)
@@ -72,21 +101,157 @@ def cpu_baseline(sample=(64, 48, 32), steps=4):
     orc.close()
     return {
         "value": n * steps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
-        "sample": "CPU restatement of jammy4536/SPH (original needs Eigen+nanoflann): "
-                  "3-D dam break, fluid %dx%dx%d, %d particles, %d step(s), %.1f s"
-                  % (sample[0], sample[1], sample[2], n, steps, dt),
+        "sample": "CPU restatement of jammy4536/SPH (original needs Eigen+nanoflann), 1 core: "
+                  "3-D dam break, fluid %dx%dx%d, %d particles, %d step(s), %.1f s; the 2-D WCXSPH "
+                  "program as shipped (%d particles), 20 steps, %.2f s = %.0f particle-steps/s"
+                  % (sample[0], sample[1], sample[2], n, steps, dt, n1, dt1, n1 * 20 / dt1),
     }
+
+
+class Legs:
+    """The timed legs of one rank; `sync` brackets a timed region (device sync, and a barrier
+    over the ranks when there are several), `agree_max` folds a list of floats over the ranks."""
+
+    def __init__(self, sim, args, sync, agree_max):
+        self.sim, self.args, self.sync, self.agree_max = sim, args, sync, agree_max
+
+    def timed(self, nsteps):
+        sim = self.sim
+        sim.profile_enable(True)
+        sim.profile_read()
+        r0 = sim.scalars()
+        self.sync()
+        t0 = time.perf_counter()
+        sc = sim.step(nsteps)
+        self.sync()
+        elapsed = time.perf_counter() - t0
+        prof = sim.profile_read()
+        sim.profile_enable(False)
+        launches = max(prof["pair_launches"], 1)
+        elapsed, pair_ms, rb_ms, dr_ms = self.agree_max([
+            elapsed, prof["pair_ms"] / launches, prof["rebuild_ms"] / max(prof["rebuilds"], 1),
+            prof["pair_ms_by_kind"][2] / max(prof["pair_launches_by_kind"][2], 1)])
+        return {
+            "elapsed": elapsed, "steps": nsteps, "ms_per_step": elapsed / nsteps * 1e3,
+            "pair_ms": pair_ms, "pair_launches": prof["pair_launches"],
+            "launches_on_step_lists": prof["pair_launches_by_kind"][1],
+            "rebuilds": prof["rebuilds"], "rebuild_ms_each": rb_ms,
+            "draws": prof["pair_launches_by_kind"][2], "draw_ms_each": dr_ms,
+            "step_redos": sc["step_redos"] - r0["step_redos"], "hit_pairs": sc["hit_pairs"],
+            "t": sc["t"], "dt": sc["dt"],
+        }
+
+    def run(self):
+        """At rest: W warm-up + K_rest timed steps from t = 0.  Then the pre-roll, W warm-up
+        steps and exactly K timed steps in developed flow, then one DensityReinit."""
+        a, sim = self.args, self.sim
+        done = 0
+        for _ in range(a.warmup):
+            sim.step(1)
+            done += 1
+        k_rest = min(a.steps, 10)
+        rest = self.timed(k_rest)
+        done += k_rest
+        while done < a.preroll:
+            m = min(20, a.preroll - done)
+            sim.step(m)
+            done += m
+        for _ in range(a.warmup):
+            sim.step(1)
+        dev = self.timed(a.steps)
+        self.sync()
+        t0 = time.perf_counter()
+        sim.density_reinit()
+        self.sync()
+        reinit_ms = self.agree_max([(time.perf_counter() - t0) * 1e3])[0]
+        return rest, dev, reinit_ms
+
+
+def rooflines(n_launch, n_total, dev, pairs_per_particle):
+    """`roofline` of the dominant kernel (the fused pair/update launch of a sweep) and of the
+    list rebuild, from the launch durations measured with HIP events in the timed region.
+    n_launch: particles one launch covers (the slowest rank's in a slab run)."""
+    b_alg = (B_ALG_PAIR + B_ALG_UPDATE) * n_launch
+    ach = b_alg / (dev["pair_ms"] * 1e-3) / 1e9
+    f_alg = FLOP_PER_PAIR * pairs_per_particle * n_launch
+    ach_tf = f_alg / (dev["pair_ms"] * 1e-3) / 1e12
+    pair = {
+        "kernel": "k_pair<3,xsph,fused> (Forces + wall reset + Newmark update + EOS, one launch per sweep)",
+        "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        "traffic": None, "algorithmic_bytes_per_launch": b_alg, "kernel_ms": dev["pair_ms"],
+        "launches": dev["pair_launches"], "algorithmic_bytes_per_particle_sweep": B_ALG_PAIR + B_ALG_UPDATE,
+        "limiter": "vector-instruction issue and the gather -> LDS transpose chain (not bytes): see fp64 and DESIGN.md",
+        "fp64": {"achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": ach_tf / FP64_PEAK_TFLOPS, "flop_per_pair": FLOP_PER_PAIR},
+    }
+    rb = None
+    if dev["rebuilds"]:
+        b_rb = B_ALG_REBUILD * n_launch
+        a_rb = b_rb / (dev["rebuild_ms_each"] * 1e-3) / 1e9
+        rb = {
+            "kernel": "list rebuild (bbox, hash, radix sort, reorder, cell table, k_build_list dominant)",
+            "bound": "hbm", "achieved": a_rb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_rb / HBM_PEAK_GBS,
+            "traffic": None, "algorithmic_bytes_per_rebuild": b_rb, "rebuild_ms": dev["rebuild_ms_each"],
+            "rebuilds": dev["rebuilds"], "algorithmic_bytes_per_particle": B_ALG_REBUILD,
+        }
+    return pair, rb
+
+
+def result_line(args, n_gpus, n, n_launch, workload, rest, dev, reinit_ms, scaling, extra_config):
+    value = n * args.steps / dev["elapsed"]
+    pairs = (dev["hit_pairs"] + n) / n
+    pair, rb = rooflines(n_launch, n, dev, pairs)
+    frame_ms = 10 * dev["ms_per_step"] + reinit_ms
+    cfg = {
+        "workload": workload,
+        "particles": n, "sweeps_per_step": 8, "force_evals_per_s": value * 8,
+        "flow": "developed: %d steps advanced untimed before the warm-up (t = %.3f s at the end of the timed region)"
+                % (args.preroll, dev["t"]),
+        "pairs_in_radius_per_particle": pairs,
+        "list_rebuilds": dev["rebuilds"], "rebuild_ms_each": dev["rebuild_ms_each"],
+        "step_list_draws": dev["draws"], "draw_ms_each": dev["draw_ms_each"],
+        "pair_launches_on_step_lists": dev["launches_on_step_lists"],
+        "step_redos": dev["step_redos"],
+        "at_rest": {
+            "value": n * rest["steps"] / rest["elapsed"], "steps": rest["steps"], "ms_per_step": rest["ms_per_step"],
+            "pair_kernel_ms": rest["pair_ms"], "list_rebuilds": rest["rebuilds"],
+            "roofline_frac": (B_ALG_PAIR + B_ALG_UPDATE) * n_launch / (rest["pair_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "the lattice at rest from t = 0: no list rebuild falls into the region (best case)",
+        },
+        "reinit_ms": reinit_ms,
+        "frame": {"what": "10 steps + 1 DensityReinit, the reference's frame loop (WCXSPH3D.cpp:475-482)",
+                  "ms": frame_ms, "particle_steps_per_s": n * 10 / (frame_ms * 1e-3)},
+    }
+    cfg.update(extra_config)
+    out = {
+        "metric": "particle-steps/sec (3-D WCXSPH dam break)",
+        "value": value, "unit": "particle-steps/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dev["ms_per_step"],
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": cfg, "roofline": pair,
+    }
+    if rb:
+        out["roofline_rebuild"] = rb
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--fluid", type=str, default="640x320x48", help="fluid block per GPU, NXxNYxNZ")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preroll", type=int, default=600,
+                    help="steps advanced untimed before the warm-up, so that the timed region is developed flow")
+    ap.add_argument("--fluid", type=str, default="",
+                    help="fluid block NXxNYxNZ: per GPU (weak scaling, default 640x320x48) or in all "
+                         "(strong scaling, default 2048x1024x48)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="several GPUs: grow the case with the ranks (weak) or cut one fixed case into slabs (strong)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--skin", type=float, default=0.0, help="tuning: candidate-list skin fraction (0 = library default)")
-    ap.add_argument("--inner", type=float, default=0.0, help="tuning: working-list skin fraction (0 = default, <0 = off)")
+    ap.add_argument("--skin", type=float, default=0.0, help="tuning: candidate-list skin fraction (0 = follow the motion)")
+    ap.add_argument("--inner", type=float, default=0.0, help="tuning: step-list margin (0 = automatic, <0 = no step lists)")
     args = ap.parse_args()
 
     import torch
@@ -103,6 +268,8 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 
+    if not args.fluid:
+        args.fluid = "%dx%dx%d" % (C4 if (world > 1 and args.scaling == "strong") else C3)
     nx, ny, nz = (int(v) for v in args.fluid.lower().split("x"))
     if world > 1:
         from sph_amd import domain
@@ -116,53 +283,14 @@ def main():
     n = sim.npts
     setup_s = time.perf_counter() - t_setup
 
-    for _ in range(args.warmup):
-        sim.step(1)
-    sim.profile_enable(True)
-    sim.profile_read()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sc = sim.step(args.steps)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    prof = sim.profile_read()
-    sim.profile_enable(False)
-
-    value = n * args.steps / elapsed
-    pair_ms = prof["pair_ms"] / max(prof["pair_launches"], 1)
-    b_alg = (B_ALG_PAIR + B_ALG_UPDATE) * n
-    f_alg = FLOP_PER_PAIR * (sc["hit_pairs"] + n)
-    ach_gbs = b_alg / (pair_ms * 1e-3) / 1e9
-    ach_tf = f_alg / (pair_ms * 1e-3) / 1e12
-    out = {
-        "metric": "particle-steps/sec (3-D WCXSPH dam break)",
-        "value": value, "unit": "particle-steps/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {
-            "workload": "%s: WCXSPH3D dam break, Pstep 0.1, fluid %dx%dx%d + walls, box %.1fx%.1fx%.1f"
-                        % ({(640, 320, 48): "C3", (2048, 1024, 48): "C4 on one GPU"}.get((nx, ny, nz), "custom size"),
-                           nx, ny, nz, case.box[0], case.box[1], case.box[2]),
-            "particles": n, "wall_particles": sim.bound_parts, "sweeps_per_step": 8,
-            "force_evals_per_s": value * 8,
-            "pairs_in_radius_per_particle": (sc["hit_pairs"] + n) / n,
-            "list_rebuilds": prof["rebuilds"], "rebuild_ms_each": prof["rebuild_ms"] / max(prof["rebuilds"], 1),
-            "step_redos": sc["step_redos"], "setup_s": setup_s,
-        },
-        "roofline": {
-            "kernel": "k_pair<3,xsph,fused> (Forces + wall reset + Newmark update + EOS, one launch per sweep)",
-            "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach_gbs / HBM_PEAK_GBS, "traffic": measured_traffic((nx, ny, nz), n),
-            "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE of this workload, profiles/pair_traffic.json)",
-            "algorithmic_bytes_per_launch": b_alg,
-            "kernel_ms": pair_ms, "launches": prof["pair_launches"],
-            "algorithmic_bytes_per_particle_sweep": B_ALG_PAIR + B_ALG_UPDATE,
-            "fp64": {"achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": ach_tf / FP64_PEAK_TFLOPS, "flop_per_pair": FLOP_PER_PAIR},
-        },
-    }
+    rest, dev, reinit_ms = Legs(sim, args, torch.cuda.synchronize, lambda v: v).run()
+    name = {C3: "C3", C4: "C4 on one GPU"}.get((nx, ny, nz), "custom size")
+    out = result_line(args, 1, n, n, "%s: WCXSPH3D dam break, Pstep 0.1, fluid %dx%dx%d + walls, box %.1fx%.1fx%.1f, "
+                      "developed flow" % (name, nx, ny, nz, case.box[0], case.box[1], case.box[2]),
+                      rest, dev, reinit_ms, "weak", {"wall_particles": sim.bound_parts, "setup_s": setup_s})
+    out["roofline"]["traffic"] = measured_traffic((nx, ny, nz), n)
+    out["roofline"]["traffic_unit"] = ("bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE of this workload and this kernel "
+                                       "source, profiles/pair_traffic.json; null when the committed counter run is of another)")
     sim.close()
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()

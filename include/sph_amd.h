@@ -78,9 +78,11 @@ typedef struct sph_params {
     double   slab_lo, slab_hi;
     int32_t  migrate;
     int32_t  reserved_;
-    /* Implementation knob, off at 0: with a value > 0 (e.g. 0.025) the first sweep of a step
-     * writes out the candidates within search radius * (1 + value) and the other sweeps walk
-     * only those; a step whose particles outrun that margin is redone on the full lists. */
+    /* Implementation knob.  Step lists: once per step, on the positions the step's second sweep
+     * starts from, the candidates within search radius * (1 + margin) are copied out of every
+     * candidate row, and the sweeps walk only those; a step whose particles outrun the margin
+     * is redone on the candidate lists.  0: used when the candidate skin is wide enough for them to pay, margin chosen from
+     * the travel seen between a step's sweeps; > 0: always, with this margin; < 0: never. */
     double   inner_skin_frac;
 } sph_params;
 
@@ -173,6 +175,10 @@ int sph_neighbours(sph_ctx* ctx, int32_t which_state, uint64_t* row_offsets, uin
 int sph_profile_enable(sph_ctx* ctx, int32_t on);
 int sph_profile_read(sph_ctx* ctx, double* pair_ms_total, uint64_t* pair_launches,
                      double* rebuild_ms_total, uint64_t* rebuilds);
+/* More detail (call it BEFORE sph_profile_read, which clears the records): [0] pair launches that
+ * walked the candidate lists, [1] pair launches that walked the step lists, [2] draws of the step
+ * lists from the candidates.  Both arrays have three entries. */
+int sph_profile_read_kinds(sph_ctx* ctx, double* ms3, uint64_t* launches3);
 
 /* ---- slab decomposition ----------------------------------------------------------------
  * No counterpart in the reference.  A rank owns the particles whose x lay in its interval at
@@ -205,6 +211,9 @@ int sph_upload_global_ids(sph_ctx* ctx, const uint32_t* gids);
  * sph_download_global_ids reports (entry k belongs to the particle with that global index). */
 int sph_local_count(sph_ctx* ctx, uint64_t* npts, uint64_t* migrated_in, uint64_t* migrated_out);
 int sph_download_global_ids(sph_ctx* ctx, uint32_t* gids);
+/* Size of the halo since the last list rebuild: particles this rank sends to its left [0] and
+ * right [1] neighbour at every sweep (64 bytes each), and receives from them. */
+int sph_halo_counts(sph_ctx* ctx, uint64_t* sent2, uint64_t* received2);
 /* Moves this rank's x-interval (all ranks call it with planes that still tile the line).  With
  * migrate on, the particles now outside the interval are handed over at the next step's list
  * rebuild; a particle travels one slab per rebuild, so move a plane by less than a slab, and by

@@ -22,11 +22,11 @@ PROGRAM_WCSPH, PROGRAM_WCXSPH, PROGRAM_WCXSPH3D = 0, 1, 2
 SYMBOLS = (
     "sph_create", "sph_destroy", "sph_last_error", "sph_upload", "sph_download", "sph_forces",
     "sph_zero_boundary_forces", "sph_step", "sph_step_noalloc", "sph_sweeps", "sph_get_scalars", "sph_set_dt",
-    "sph_density_reinit", "sph_neighbours", "sph_profile_enable", "sph_profile_read",
+    "sph_density_reinit", "sph_neighbours", "sph_profile_enable", "sph_profile_read", "sph_profile_read_kinds",
     "sph_case_default", "sph_case_params", "sph_case_init",
     "sph_set_transport", "sph_upload_global_ids", "sph_rccl_unique_id", "sph_use_rccl",
     "sph_case_init_range", "sph_case_histogram_x", "sph_local_count", "sph_download_global_ids",
-    "sph_set_slab_interval",
+    "sph_set_slab_interval", "sph_halo_counts",
 )
 
 
@@ -113,6 +113,7 @@ def lib():
     L.sph_profile_enable.argtypes = [vp, C.c_int32]
     L.sph_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.sph_profile_read_kinds.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sph_case_default.argtypes = [C.c_int32, C.POINTER(Case)]
     L.sph_case_params.argtypes = [C.POINTER(Case), C.POINTER(Params), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]
@@ -122,6 +123,7 @@ def lib():
     L.sph_local_count.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sph_download_global_ids.argtypes = [vp, vp]
     L.sph_set_slab_interval.argtypes = [vp, C.c_double, C.c_double]
+    L.sph_halo_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sph_rccl_unique_id.argtypes = [vp]
     L.sph_use_rccl.argtypes = [vp, vp]
     L.sph_case_init_range.argtypes = [C.POINTER(Case), C.c_double, C.c_double, C.POINTER(Fields), vp,
@@ -329,6 +331,12 @@ class Sim:
         self._chk(lib().sph_local_count(self._h, C.byref(n), C.byref(mi), C.byref(mo)), "sph_local_count")
         return int(n.value), int(mi.value), int(mo.value)
 
+    def halo_counts(self):
+        """Particles sent to / received from the (left, right) neighbour at every sweep."""
+        s, r = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        self._chk(lib().sph_halo_counts(self._h, s, r), "sph_halo_counts")
+        return (int(s[0]), int(s[1])), (int(r[0]), int(r[1]))
+
     def set_slab_interval(self, lo, hi):
         self._chk(lib().sph_set_slab_interval(self._h, lo, hi), "sph_set_slab_interval")
 
@@ -382,6 +390,17 @@ class Sim:
         self._chk(lib().sph_profile_enable(self._h, 1 if on else 0), "sph_profile_enable")
 
     def profile_read(self):
+        """Pair-kernel and rebuild durations since the last read; `by_kind`: pair launches that
+        walked the candidate lists / pair launches that walked the step lists / draws of the
+        step lists."""
+        kms, kn = (C.c_double * 3)(), (C.c_uint64 * 3)()
+        self._chk(lib().sph_profile_read_kinds(self._h, kms, kn), "sph_profile_read_kinds")
+        out = self._profile_read()
+        out["pair_ms_by_kind"] = [float(v) for v in kms]
+        out["pair_launches_by_kind"] = [int(v) for v in kn]
+        return out
+
+    def _profile_read(self):
         pm, rm = C.c_double(), C.c_double()
         pn, rn = C.c_uint64(), C.c_uint64()
         self._chk(lib().sph_profile_read(self._h, C.byref(pm), C.byref(pn), C.byref(rm), C.byref(rn)),

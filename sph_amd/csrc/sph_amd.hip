@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,7 @@ constexpr int NREC = 3;
 
 struct EventPair {
     hipEvent_t a, b;
+    int kind; /* pair launches: 0 walked the candidate lists, 1 the step lists */
 };
 
 }  // namespace
@@ -76,8 +78,18 @@ struct sph_ctx {
     uint32_t* nbr_in = nullptr;
     uint32_t nbr_in_cap_k = 0;
     uint32_t* cnt_in = nullptr;
-    double inner_frac = 0.0, r_in2 = 0, limit_in = 0, outer_budget = 0; /* working lists are opt-in */
-    const uint32_t* use_nbr = nullptr; /* what the pair kernel walks in the step under way */
+    /* Step lists: the step's second sweep draws them from the candidates with radius
+     * R*(1+inner_frac), the later sweeps walk them, and so does the next step's first sweep when
+     * they still cover it (step_lists_valid).  inner_mode 0: used when the candidate skin is wide
+     * enough to pay, inner_frac following the travel seen between a step's later sweeps;
+     * 1: always, with the caller's inner_frac; -1: never. */
+    int inner_mode = 0;
+    double inner_frac = 0.02, r_in2 = 0, limit_in = 0, outer_budget = 0;
+    bool two_level = false;        /* decided at each rebuild */
+    bool step_lists_valid = false; /* nbr_in serves the positions state n+1 holds now */
+    double in_travel = 0;          /* running estimate of the travel between a step's second and last sweep */
+    double two_level_min_skin = 0.08, skin_k1 = 2.2, skin_k2 = 12.0;
+    const uint32_t* use_nbr = nullptr; /* what the pair kernel walks in the sweep under way */
     const uint32_t* use_cnt = nullptr;
     uint32_t* need = nullptr;
     GridParams grid;
@@ -102,6 +114,7 @@ struct sph_ctx {
     double* part2_use = nullptr;
     double* scratch = nullptr; /* device address of this device's scratch array */
     bool no_alloc = false;     /* the call under way may not allocate or free device memory */
+    bool trace = false;        /* SPH_TRACE=1: a line per list rebuild on stderr */
     double* bbox_part = nullptr;
     double* bbox_host = nullptr; /* pinned */
     uint32_t* need_host = nullptr; /* pinned, 8 words */
@@ -137,7 +150,7 @@ struct sph_ctx {
     hipStream_t comm = nullptr;
     hipEvent_t ev_packed = nullptr, ev_recvd = nullptr;
     sph_transport tr;
-    bool have_tr = false;
+    std::atomic<bool> have_tr{false}; /* sph_use_rccl may run on a second host thread while the caller gives up waiting */
     double* red_dev = nullptr;
     uint32_t iL_end = 0, iR_begin = 0; /* owned ranges [0,iL_end) and [iR_begin,n) touch a halo */
     void* rccl = nullptr;              /* state of the built-in RCCL transport */
@@ -149,6 +162,8 @@ struct sph_ctx {
     size_t ev_used = 0;
     std::vector<EventPair> rb_pool;
     size_t rb_used = 0;
+    std::vector<EventPair> dr_pool; /* draws of the step lists */
+    size_t dr_used = 0;
 };
 
 namespace {
@@ -282,6 +297,12 @@ void launch_hash(sph_ctx* c, const Rec* r, uint32_t m, const uint32_t* drop, uin
     else hipLaunchKernelGGL(k_hash<2>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, c->grid, drop, keys);
 }
 
+/* Where the draw's 16-byte entries and the particles' rebuild-time cells live: in the spare
+ * record array (64 bytes per particle, free between a reorder and the next one), behind the
+ * list build's 16-byte entries. */
+inline DPos* dpos_of(sph_ctx* c) { return (DPos*)((char*)c->rec_alt + (size_t)c->cap * 16); }
+inline uint32_t* cellc_of(sph_ctx* c) { return (uint32_t*)((char*)c->rec_alt + (size_t)c->cap * 32); }
+
 int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
     const uint32_t* hb = c->n_halo ? c->hbeg : nullptr;
     const uint32_t* he = c->n_halo ? c->hend : nullptr;
@@ -289,15 +310,15 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
      * (in the spare record array, which nothing else uses between a reorder and the next one) */
     const uint32_t m = c->n + c->n_halo;
     hipLaunchKernelGGL(k_fill_pos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, wall_ids(c), m, c->grid, c->dim,
-                       (Pos*)c->rec_alt);
+                       (Pos*)c->rec_alt, cellc_of(c));
     const Pos* pos = (const Pos*)c->rec_alt;
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
         if (c->dim == 3)
-            hipLaunchKernelGGL(k_build_list<3>, dim3((c->n + 63u) / 64u), dim3(SPH_BLOCK), 0, c->stream, r, pos, c->n, c->grid, c->cbeg,
+            hipLaunchKernelGGL(k_build_list<3>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, pos, c->n, c->grid, c->cbeg,
                                c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below, hb, he);
         else
-            hipLaunchKernelGGL(k_build_list<2>, dim3((c->n + 63u) / 64u), dim3(SPH_BLOCK), 0, c->stream, r, pos, c->n, c->grid, c->cbeg,
+            hipLaunchKernelGGL(k_build_list<2>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, pos, c->n, c->grid, c->cbeg,
                                c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below, hb, he);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -601,14 +622,26 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
             lo[d] = std::min(lo[d], c->bbox_host[b * 6 + d]);
             hi[d] = std::max(hi[d], c->bbox_host[b * 6 + 3 + d]);
         }
-    if (c->skin_auto && for_step && c->step_travel > 0) {
-        /* Cost per step ~ pair work, of which (measured) a little under half grows like (1+s)^dim,
-         * + a rebuild (about half a step) every 0.5*s*R/travel steps: least near
-         * s = sqrt(2.2 * travel/R / dim); and lists should serve at least two steps. */
-        const double u = c->step_travel / std::sqrt(c->prm.search_radius_sq);
-        const double s_opt = std::max(std::sqrt(2.2 * u / dim), 5.0 * u);
-        c->skin_frac = std::min(0.5, std::max(0.03, s_opt));
+    c->step_lists_valid = false; /* the order of the particles changes */
+    const double Rs = std::sqrt(c->prm.search_radius_sq);
+    if (c->inner_mode == 0) {
+        /* the step lists' margin: twice the travel seen between a step's second and last sweep
+         * (2 % of the radius until there is a measurement) */
+        c->inner_frac = c->in_travel > 0 ? std::min(0.08, std::max(0.004, 5.0 * c->in_travel / Rs)) : 0.02;
     }
+    if (c->skin_auto && for_step && c->step_travel > 0) {
+        /* Cost per step ~ pair work, of which a part grows like (1+s)^dim, + a rebuild every
+         * 0.5*s*R/travel steps: least near s = sqrt(k * travel/R / dim), and lists should serve at
+         * least two steps.  k = 2.2 (measured) when every sweep walks the candidates; with step
+         * lists no sweep does (only the draw reads them, once per step), and a wider skin (k = 12) pays. */
+        const double u = c->step_travel / Rs;
+        const double s1 = std::min(0.5, std::max(0.03, std::max(std::sqrt(c->skin_k1 * u / dim), 5.0 * u)));
+        const double s2 = std::min(0.5, std::max(0.03, std::max(std::sqrt(c->skin_k2 * u / dim), 5.0 * u)));
+        const bool two = c->inner_mode == 1 || (c->inner_mode == 0 && s2 >= c->two_level_min_skin);
+        c->skin_frac = two ? s2 : s1;
+    }
+    c->two_level = for_step && c->inner_mode >= 0 && c->inner_frac < c->skin_frac &&
+                   (c->inner_mode == 1 || c->skin_frac >= c->two_level_min_skin);
     const double r_list = std::sqrt(c->prm.search_radius_sq) * (1.0 + c->skin_frac);
     const double reach = r_list * (1.0 + 1e-6); /* halo selection distance beyond a neighbour's extent */
     double thr_send[2] = {0, 0};
@@ -685,6 +718,8 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     if (ncells == 0) return fail(c, SPH_ESTATE, "cell grid exceeds its table");
     g.ncells = (uint32_t)ncells;
     c->grid = g;
+    /* the draw refers to a particle's cell through a packed word */
+    if (g.n[0] > CELLC_MAX_X || g.n[1] > CELLC_MAX_YZ || g.n[2] > CELLC_MAX_YZ) c->two_level = false;
 
     /* sort the owned particles by cell */
     launch_hash(c, c->rec[src], m_sort, drop, c->keys);
@@ -796,7 +831,7 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     c->r_list2 = r_list * r_list;
     c->disp_limit = 0.5 * (r_list - std::sqrt(c->prm.search_radius_sq)) * 0.999;
     {
-        /* working lists: radius R*(1+inner_frac), never beyond the candidate radius */
+        /* step lists: radius R*(1+inner_frac), never beyond the candidate radius */
         const double R = std::sqrt(c->prm.search_radius_sq);
         const double r_in = std::min(R * (1.0 + c->inner_frac), r_list);
         c->r_in2 = r_in * r_in;
@@ -814,9 +849,15 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     /* travel bound restarts */
     const double z[2] = {0.0, c->disp_limit};
     HIPCHK(hipMemcpyAsync(&c->S->disp, z, sizeof z, hipMemcpyHostToDevice, c->stream));
+    const double zi[2] = {0.0, c->limit_in};
+    HIPCHK(hipMemcpyAsync(&c->S->disp_in, zi, sizeof zi, hipMemcpyHostToDevice, c->stream));
     c->disp_host = 0;
     c->list_valid = true;
     ++c->rebuilds;
+    if (c->trace)
+        fprintf(stderr, "[sph] rebuild %llu: n %u skin %.4f two_level %d inner %.5f step_travel/R %.5f in_travel/R %.3e rows %u\n",
+                (unsigned long long)c->rebuilds, c->n, c->skin_frac, (int)c->two_level, c->inner_frac,
+                c->step_travel / std::sqrt(c->prm.search_radius_sq), c->in_travel / std::sqrt(c->prm.search_radius_sq), c->cap_k);
     if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
     return SPH_OK;
 }
@@ -847,21 +888,18 @@ NState n_state(sph_ctx* c) {
 
 /* Launches the pair kernel over particles [first, first+count); its workgroups leave their
  * partials in slots [part_base, part_base + grid) of each field of c->part. */
-template <bool FUSED, bool FILTER = false>
+template <bool FUSED>
 int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out, int zero_wall, uint32_t first,
                 uint32_t count, uint32_t part_base, uint32_t part_n) {
     if (count == 0) return SPH_OK;
     NState ns = n_state(c);
     dim3 g(pairblocks(count)), b(PAIR_BLOCK);
-    /* FILTER: walk the candidate lists and write the step's working lists */
-    const uint32_t* walk = FILTER ? c->nbr : c->use_nbr;
-    const uint32_t* walk_cnt = FILTER ? c->cnt : c->use_cnt;
     /* record arrays of 4 GiB and more need 64-bit piece addresses */
     const bool wide = (uint64_t)c->cap * sizeof(Rec) >= (1ull << 32);
-#define LP(D, X, W)                                                                                                   \
-    hipLaunchKernelGGL((k_pair<D, X, FUSED, FILTER, W>), g, b, 0, c->stream, c->dp, rin, walk, c->cap_k, walk_cnt, o, \
-                       store_out, zero_wall, ns, wall_ids(c), rout, c->pp, c->S, c->part_use, first, count,           \
-                       part_base, part_n, c->nbr_in, c->cnt_in, c->r_in2)
+#define LP(D, X, W)                                                                                                  \
+    hipLaunchKernelGGL((k_pair<D, X, FUSED, W>), g, b, 0, c->stream, c->dp, rin, c->use_nbr, c->cap_k, c->use_cnt, o, \
+                       store_out, zero_wall, ns, wall_ids(c), rout, c->pp, c->S, c->part_use, first, count,          \
+                       part_base, part_n)
     if (c->dim == 3) { if (wide) LP(3, true, true); else LP(3, true, false); }
     else if (c->xsph) { if (wide) LP(2, true, true); else LP(2, true, false); }
     else { if (wide) LP(2, false, true); else LP(2, false, false); }
@@ -870,11 +908,40 @@ int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out
     return SPH_OK;
 }
 
-/* the fused sweep launch; `filter` on a step's first sweep when working lists are in use */
-int launch_sweep(sph_ctx* c, bool filter, const Rec* rin, Rec* rout, OutState o, int store_out, uint32_t first,
+/* the fused sweep launch */
+int launch_sweep(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out, uint32_t first,
                  uint32_t count, uint32_t part_base, uint32_t part_n) {
-    if (filter) return launch_pair<true, true>(c, rin, rout, o, store_out, 1, first, count, part_base, part_n);
-    return launch_pair<true, false>(c, rin, rout, o, store_out, 1, first, count, part_base, part_n);
+    return launch_pair<true>(c, rin, rout, o, store_out, 1, first, count, part_base, part_n);
+}
+
+/* Draws the step lists from the candidate lists on the positions held in `r` (owned and halo
+ * particles), and starts their travel bound. */
+int draw_step_lists(sph_ctx* c, const Rec* r) {
+    const uint32_t m = c->n + c->n_halo;
+    EventPair* ev = nullptr;
+    if (c->profile && !(c->no_alloc && c->dr_used == c->dr_pool.size())) {
+        if (c->dr_used == c->dr_pool.size()) {
+            EventPair e;
+            HIPCHK(hipEventCreate(&e.a));
+            HIPCHK(hipEventCreate(&e.b));
+            c->dr_pool.push_back(e);
+        }
+        ev = &c->dr_pool[c->dr_used++];
+        HIPCHK(hipEventRecord(ev->a, c->stream));
+    }
+    hipLaunchKernelGGL(k_fill_dpos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, cellc_of(c), m, c->grid, c->dim, dpos_of(c));
+    const double edge = 1.0 / c->grid.inv[0];
+    const float r2f = (float)(c->r_in2 * (1.0 + list_float_margin(edge, std::sqrt(c->r_list2))));
+    const dim3 g(pairblocks(c->n)), b(SPH_BLOCK); /* 64 particles per workgroup, a multiple of 8 workgroups */
+    if (c->dim == 3)
+        hipLaunchKernelGGL(k_draw_lists<3>, g, b, 0, c->stream, dpos_of(c), c->n, c->nbr, c->cap_k, c->cnt, (float)edge, r2f,
+                           c->nbr_in, c->cnt_in, c->S);
+    else
+        hipLaunchKernelGGL(k_draw_lists<2>, g, b, 0, c->stream, dpos_of(c), c->n, c->nbr, c->cap_k, c->cnt, (float)edge, r2f,
+                           c->nbr_in, c->cnt_in, c->S);
+    HIPCHK(hipGetLastError());
+    if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
+    return SPH_OK;
 }
 
 int pack_n_into(sph_ctx* c, Rec* dst) {
@@ -917,19 +984,19 @@ void fill_scalars(sph_ctx* c, sph_scalars* out) {
 /* One sweep's pair/update launches.  A single domain is one launch.  A slab first does the
  * layers next to its neighbours, hands their new records to the transport on the
  * communication stream, and computes its interior while they travel. */
-int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, bool filter, uint32_t* part_n_out) {
+int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, uint32_t* part_n_out) {
     const uint32_t n = c->n;
     OutState o = out_state(c, SPH_STATE_NP1);
     if (!c->dist) {
         *part_n_out = pairblocks(n);
-        return launch_sweep(c, filter, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 0, n, 0, *part_n_out);
+        return launch_sweep(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 0, n, 0, *part_n_out);
     }
     const uint32_t nL = c->iL_end, nR = n - c->iR_begin, nI = c->iR_begin - c->iL_end;
     const uint32_t bL = nL ? pairblocks(nL) : 0, bR = nR ? pairblocks(nR) : 0, bI = nI ? pairblocks(nI) : 0;
     const uint32_t part_n = bL + bR + bI;
     *part_n_out = part_n;
-    CHK(launch_sweep(c, filter, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 0, nL, 0, part_n));
-    CHK(launch_sweep(c, filter, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, c->iR_begin, nR, bL, part_n));
+    CHK(launch_sweep(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 0, nL, 0, part_n));
+    CHK(launch_sweep(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, c->iR_begin, nR, bL, part_n));
     const size_t hc = c->halo_cap;
     for (int side = 0; side < 2; ++side)
         if (c->nsend[side])
@@ -937,7 +1004,7 @@ int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, bool filter, uint32_
                                c->send_idx + side * hc, c->nsend[side], c->sendbuf + side * hc);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev_packed, c->stream));
-    CHK(launch_sweep(c, filter, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, c->iL_end, nI, bL + bR, part_n));
+    CHK(launch_sweep(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, c->iL_end, nI, bL + bR, part_n));
     /* the exchange runs beside the interior launch */
     HIPCHK(hipStreamWaitEvent(c->comm, c->ev_packed, 0));
     CHK(exchange_bytes(c, c->sendbuf, (size_t)c->nsend[0] * sizeof(Rec), c->recvbuf, (size_t)c->nrecv[0] * sizeof(Rec),
@@ -957,39 +1024,53 @@ int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, bool filter, uint32_
     return SPH_OK;
 }
 
+/* Room for the step lists (as many rows as the candidate lists; sph_create makes it, and it is
+ * made again when the candidate rows have grown). */
+int ensure_step_lists(sph_ctx* c, bool* ok) {
+    *ok = true;
+    if (c->nbr_in && c->nbr_in_cap_k == c->cap_k && c->cnt_in) return SPH_OK;
+    CHK(dfree(c, &c->nbr_in));
+    CHK(dalloc(c, &c->nbr_in, (size_t)c->cap_k * c->own_cap));
+    /* the pair kernel fetches whole groups of a row: every entry must index the arrays */
+    HIPCHK(hipMemsetAsync(c->nbr_in, 0, sizeof(uint32_t) * (size_t)c->cap_k * c->own_cap, c->stream));
+    c->nbr_in_cap_k = c->cap_k;
+    if (!c->cnt_in) CHK(dalloc(c, &c->cnt_in, c->cap));
+    c->step_lists_valid = false;
+    return SPH_OK;
+}
+
 /* One Newmark_Beta call, or its first `nsweeps` sweeps when partial. */
 int one_step(sph_ctx* c, int nsweeps, bool partial) {
     const int subits = c->prm.subits;
     if (!partial) nsweeps = subits;
     int cur = c->b0;
+    bool allow_two = true; /* cleared when this step outran its step lists: the redo walks the candidates only */
     for (int mode = 0;; ++mode) {
         /* mode 0: keep the lists if the travel budget allows; 1: fresh lists at the step's
          * start; 2: fresh lists before every sweep (exact for any motion) */
-        const bool inner = mode == 0 && c->inner_frac > 0;
+        bool two = allow_two && mode < 2 && c->two_level && nsweeps >= 2;
         /* what is left of the budget must cover this step: the running estimate of a step's
          * travel (1.25 x) when there is one, half the budget otherwise */
-        const double budget = inner ? c->outer_budget : c->disp_limit;
-        const bool enough = c->step_travel > 0 ? c->disp_host + 1.25 * c->step_travel <= budget
-                                               : c->disp_host <= 0.5 * budget;
-        if (mode >= 1 || !c->list_valid || !c->lists_for_step || !enough)
+        const double budget0 = two ? c->outer_budget : c->disp_limit;
+        const bool enough = c->step_travel > 0 ? c->disp_host + 1.25 * c->step_travel <= budget0
+                                               : c->disp_host <= 0.5 * budget0;
+        if (mode >= 1 || !c->list_valid || !c->lists_for_step || !enough) {
             CHK(rebuild(c, c->b0, true, true));
-        const double disp_at_start = c->disp_host; /* 0 after a rebuild */
-        c->use_nbr = c->nbr;
-        c->use_cnt = c->cnt;
-        if (inner) {
-            /* room for the step's working lists, which the first sweep draws from the candidates */
-            if (!c->nbr_in || c->nbr_in_cap_k != c->cap_k) {
-                CHK(dfree(c, &c->nbr_in));
-                CHK(dalloc(c, &c->nbr_in, (size_t)c->cap_k * c->own_cap));
-                HIPCHK(hipMemsetAsync(c->nbr_in, 0, sizeof(uint32_t) * (size_t)c->cap_k * c->own_cap, c->stream));
-                c->nbr_in_cap_k = c->cap_k;
-                if (!c->cnt_in) CHK(dalloc(c, &c->cnt_in, c->cap));
-            }
-            const double z[2] = {0.0, c->limit_in};
-            HIPCHK(hipMemcpyAsync(&c->S->disp_in, z, sizeof z, hipMemcpyHostToDevice, c->stream));
+            two = allow_two && mode < 2 && c->two_level && nsweeps >= 2;
         }
+        if (two) CHK(ensure_step_lists(c, &two));
+        const double cand_budget = two ? c->outer_budget : c->disp_limit;
+        const double disp_at_start = c->disp_host; /* 0 after a rebuild */
         hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, c->stream, c->S);
         cur = c->b0;
+        /* Two-level: every sweep walks the step lists.  They are drawn from the candidates on
+         * the positions the step's second sweep starts from -- the later sweeps' positions
+         * differ from those by dt^2-sized corrections, and the next step's first sweep starts
+         * where this step ends -- and here, when the last draw does not cover the positions the
+         * step starts from (after a rebuild, or when the last step ended beyond the margin).
+         * Rows of the step lists keep the candidates' order and the kernel skips pairs outside
+         * the radius either way, so every sum is the same with or without them. */
+        if (two && !c->step_lists_valid) CHK(draw_step_lists(c, c->rec[cur]));
         for (int k = 0; k < nsweeps; ++k) {
             if (mode == 2 && k > 0) {
                 /* the start state is not needed again: let the sweep's input take its place */
@@ -999,6 +1080,8 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             int nxt = 0;
             while (nxt == cur || nxt == c->b0) ++nxt;
             const bool last = k == nsweeps - 1;
+            c->use_nbr = two ? c->nbr_in : c->nbr;
+            c->use_cnt = two ? c->cnt_in : c->cnt;
             EventPair* ev = nullptr;
             if (c->profile && !(c->no_alloc && c->ev_used == c->ev_pool.size())) {
                 if (c->ev_used == c->ev_pool.size()) {
@@ -1008,19 +1091,25 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
                     c->ev_pool.push_back(e);
                 }
                 ev = &c->ev_pool[c->ev_used++];
+                ev->kind = two ? 1 : 0;
                 HIPCHK(hipEventRecord(ev->a, c->stream));
             }
             uint32_t part_n = 0;
-            CHK(sweep_launches(c, cur, nxt, last, inner && k == 0, &part_n));
-            if (inner && k == 0) { /* the first sweep has written the step's working lists */
-                c->use_nbr = c->nbr_in;
-                c->use_cnt = c->cnt_in;
-            }
+            CHK(sweep_launches(c, cur, nxt, last, &part_n));
             if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
             hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS, PART_FIELDS), dim3(SPH_BLOCK), 0, c->stream, c->part_use, part_n, PART_FIELDS,
                                c->part2_use);
+            /* what reads the positions just written decides which travel bound is checked: the
+             * next sweep through the candidate lists (out to R), the draw through the candidate
+             * lists (out to the step lists' radius), or the next sweep through the step lists */
+            double cand_limit = -1.0;
+            if (mode < 2) {
+                if (!two) cand_limit = c->disp_limit;
+                else if (k == 0) cand_limit = c->outer_budget;
+            }
             hipLaunchKernelGGL(k_sweep_finalize, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->part2_use, k,
-                               (last && !partial) ? 1 : (last ? 2 : 0), mode == 2 ? 0 : (inner ? 2 : 1));
+                               (last && !partial) ? 1 : (last ? 2 : 0), cand_limit, (two && k >= 1) ? 1 : 0, 0);
+            if (two && k == 0 && !last) CHK(draw_step_lists(c, c->rec[nxt]));
             cur = nxt;
         }
         CommitArgs a;
@@ -1048,13 +1137,14 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
         }
         HIPCHK(hipGetLastError());
         CHK(read_scalars(c));
+        double disp_in_seen = c->S_host->disp_in;
         if (c->dist) {
             /* the ranks agree on the maxima, the sums and on whether to redo the step; the
              * time step and the commit follow from the agreed values */
             DevScalars& s = *c->S_host;
-            double vmax[4] = {s.maxmu, s.maxf, (double)s.violation, s.disp};
+            double vmax[5] = {s.maxmu, s.maxf, (double)s.violation, s.disp, s.disp_in};
             double vsum[3] = {s.errsum0, s.errsum, (double)s.hit_pairs};
-            CHK(allreduce_host(c, vmax, 4, 0));
+            CHK(allreduce_host(c, vmax, 5, 0));
             CHK(allreduce_host(c, vsum, 3, 1));
             hipLaunchKernelGGL(k_apply_global, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, vmax[0], vmax[1], vsum[0], vsum[1],
                                vsum[2], vmax[2] != 0.0 ? 1 : 0, partial ? 0 : 1);
@@ -1065,11 +1155,19 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             HIPCHK(hipGetLastError());
             CHK(read_scalars(c));
             c->S_host->disp = vmax[3];
+            disp_in_seen = vmax[4];
         }
         c->disp_host = c->S_host->disp;
+        c->step_lists_valid = false;
         if (c->S_host->violation && mode < 2) {
-            /* the step outran its lists: it travelled at least the whole budget */
-            c->step_travel = std::max(c->step_travel, 1.25 * c->disp_limit);
+            if (two && !(disp_in_seen <= c->limit_in)) {
+                /* the later sweeps moved the particles beyond the step lists' margin */
+                c->in_travel = std::max(1.25 * disp_in_seen, 2.0 * c->in_travel);
+                allow_two = false;
+            } else {
+                /* the step outran its candidate lists: it travelled at least the whole budget */
+                c->step_travel = std::max(c->step_travel, 1.25 * cand_budget);
+            }
             ++c->redos;
             continue;
         }
@@ -1077,6 +1175,12 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             /* mode 2 restarts the bound at every sweep; what it saw is a lower bound then */
             const double seen = c->disp_host - disp_at_start;
             if (seen == seen && seen >= 0) c->step_travel = std::max(seen, 0.8 * c->step_travel);
+            if (two && disp_in_seen == disp_in_seen) {
+                c->in_travel = std::max(disp_in_seen, 0.8 * c->in_travel);
+                /* the lists drawn by this step serve the next step's first sweep if they cover
+                 * the positions this step ended on */
+                c->step_lists_valid = disp_in_seen <= c->limit_in;
+            }
         }
         break;
     }
@@ -1166,7 +1270,15 @@ int sph_create(const sph_params* p, sph_ctx** out) {
         c->skin_frac = p->skin_frac;
         c->skin_auto = false;
     }
-    if (p->inner_skin_frac > 0) c->inner_frac = p->inner_skin_frac;
+    if (p->inner_skin_frac > 0) {
+        c->inner_frac = p->inner_skin_frac;
+        c->inner_mode = 1;
+    } else if (p->inner_skin_frac < 0) {
+        c->inner_mode = -1;
+    }
+    if (const char* e = getenv("SPH_TRACE")) c->trace = atoi(e) != 0;
+    if (const char* e = getenv("SPH_TWO_LEVEL_MIN_SKIN")) c->two_level_min_skin = atof(e);
+    if (const char* e = getenv("SPH_SKIN_K2")) c->skin_k2 = atof(e);
     c->brick_log2 = c->dim == 3 ? 2u : 3u;
     if (const char* e = getenv("SPH_BRICK_LOG2")) c->brick_log2 = (uint32_t)std::min(5, std::max(0, atoi(e)));
 
@@ -1251,6 +1363,10 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     /* the pair kernel fetches whole groups of a row: every entry, used or not, must index the arrays */
     HIPCHK(hipMemsetAsync(c->nbr, 0, sizeof(uint32_t) * (size_t)c->cap_k * c->own_cap, c->stream));
     CHK(dalloc(c, &c->cnt, n));
+    if (c->inner_mode >= 0) { /* the step lists: as many rows again */
+        bool ok = true;
+        CHK(ensure_step_lists(c, &ok));
+    }
     CHK(dalloc(c, &c->need, 8));
     CHK(dalloc(c, &c->S, 1));
     HIPCHK(hipHostMalloc((void**)&c->S_host, sizeof(DevScalars)));
@@ -1337,6 +1453,7 @@ void sph_destroy(sph_ctx* c) {
     if (c->h_recv) (void)hipHostFree(c->h_recv);
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : c->rb_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : c->dr_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
     if (c->ev_recvd) (void)hipEventDestroy(c->ev_recvd);
     if (c->comm) (void)hipStreamDestroy(c->comm);
@@ -1365,6 +1482,15 @@ int sph_local_count(sph_ctx* c, uint64_t* npts, uint64_t* migrated_in, uint64_t*
     *npts = c->n;
     if (migrated_in) *migrated_in = c->migrated_in;
     if (migrated_out) *migrated_out = c->migrated_out;
+    return SPH_OK;
+}
+
+int sph_halo_counts(sph_ctx* c, uint64_t* sent2, uint64_t* received2) {
+    if (!c || !sent2 || !received2) return SPH_EINVAL;
+    for (int s = 0; s < 2; ++s) {
+        sent2[s] = c->dist ? c->nsend[s] : 0;
+        received2[s] = c->dist ? c->nrecv[s] : 0;
+    }
     return SPH_OK;
 }
 
@@ -1771,6 +1897,28 @@ int sph_profile_read(sph_ctx* c, double* pair_ms, uint64_t* pair_launches, doubl
     if (rebuild_ms) *rebuild_ms = tot;
     if (rebuilds) *rebuilds = c->rb_used;
     c->rb_used = 0;
+    c->dr_used = 0;
+    return SPH_OK;
+}
+
+int sph_profile_read_kinds(sph_ctx* c, double* ms3, uint64_t* launches3) {
+    if (!c || !ms3 || !launches3) return SPH_EINVAL;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 3; ++k) { ms3[k] = 0; launches3[k] = 0; }
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b));
+        const int k = c->ev_pool[i].kind ? 1 : 0;
+        ms3[k] += ms;
+        ++launches3[k];
+    }
+    for (size_t i = 0; i < c->dr_used; ++i) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->dr_pool[i].a, c->dr_pool[i].b));
+        ms3[2] += ms;
+        ++launches3[2];
+    }
     return SPH_OK;
 }
 

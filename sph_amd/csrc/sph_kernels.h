@@ -47,6 +47,15 @@ __device__ __forceinline__ uint32_t cell_key(const GridParams& g, int cx, int cy
     return (brick << (s0 + s1 + s2)) | local;
 }
 
+/* Workgroups are dealt round-robin to the eight XCDs, each with its own L2.  This maps
+ * blockIdx.x (grid a multiple of 8) so that every XCD works through one contiguous eighth of
+ * the cell-ordered particles: what a workgroup gathers is then what its neighbours on the same
+ * L2 have just fetched.  (Placement only changes speed, never results.) */
+__device__ __forceinline__ uint32_t xcd_contiguous_block() {
+    const uint32_t per_xcd = gridDim.x >> 3;
+    return (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+}
+
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
@@ -60,6 +69,34 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+
+/* data-parallel-primitive moves inside a quad of lanes: CTRL is a quad_perm pattern */
+template <int CTRL>
+__device__ __forceinline__ int quad_perm_i(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double quad_perm_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = quad_perm_i<CTRL>((int)(b & 0xFFFFFFFFll));
+    const int hi = quad_perm_i<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+#define QP_XOR1 0xB1 /* lanes [1,0,3,2] */
+#define QP_XOR2 0x4E /* lanes [2,3,0,1] */
+__device__ __forceinline__ double quad_sum(double v) {
+    v += quad_perm_d<QP_XOR1>(v);
+    v += quad_perm_d<QP_XOR2>(v);
+    return v;
+}
+__device__ __forceinline__ double quad_max(double v) {
+    v = fmax(v, quad_perm_d<QP_XOR1>(v));
+    v = fmax(v, quad_perm_d<QP_XOR2>(v));
     return v;
 }
 
@@ -398,17 +435,122 @@ struct __attribute__((aligned(16))) Pos {
     uint32_t id;
 };
 #define LIST_FLOAT_MARGIN 4e-5
+/* The bound above is for cells of the list radius.  When a stray particle has blown the box up
+ * the cells are stretched, and the float error grows with the edge: the margin follows it. */
+__host__ __device__ inline double list_float_margin(double edge, double r_list) {
+    const double stretch = edge / r_list;
+    return LIST_FLOAT_MARGIN * (stretch > 1.0 ? stretch : 1.0);
+}
+
+/* A particle's cell at the last rebuild, packed: x in bits 0-11, y in 12-21, z in 22-31. */
+#define CELLC_MAX_X 4096
+#define CELLC_MAX_YZ 1024
+__device__ __forceinline__ uint32_t pack_cell(int cx, int cy, int cz) {
+    return (uint32_t)cx | ((uint32_t)cy << 12) | ((uint32_t)cz << 22);
+}
+
+/* also records every particle's cell (cellc may be null), which k_fill_dpos refers to later */
 __global__ __launch_bounds__(SPH_BLOCK) void k_fill_pos(const Rec* __restrict__ rec, const uint32_t* __restrict__ id, uint32_t m,
-                                                        GridParams g, int dim, Pos* __restrict__ pos) {
+                                                        GridParams g, int dim, Pos* __restrict__ pos,
+                                                        uint32_t* __restrict__ cellc) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= m) return;
     const double x = rec[i].xv[0][0], y = rec[i].xv[1][0], z = rec[i].xv[2][0];
+    const int cx = cell_coord(x, g.lo[0], g.inv[0], g.n[0]);
+    const int cy = cell_coord(y, g.lo[1], g.inv[1], g.n[1]);
+    const int cz = dim == 3 ? cell_coord(z, g.lo[2], g.inv[2], g.n[2]) : 0;
     Pos p;
-    p.u = (float)((x - g.lo[0]) - (double)cell_coord(x, g.lo[0], g.inv[0], g.n[0]) * (1.0 / g.inv[0]));
-    p.v = (float)((y - g.lo[1]) - (double)cell_coord(y, g.lo[1], g.inv[1], g.n[1]) * (1.0 / g.inv[1]));
-    p.w = dim == 3 ? (float)((z - g.lo[2]) - (double)cell_coord(z, g.lo[2], g.inv[2], g.n[2]) * (1.0 / g.inv[2])) : 0.0f;
+    p.u = (float)((x - g.lo[0]) - (double)cx * (1.0 / g.inv[0]));
+    p.v = (float)((y - g.lo[1]) - (double)cy * (1.0 / g.inv[1]));
+    p.w = dim == 3 ? (float)((z - g.lo[2]) - (double)cz * (1.0 / g.inv[2])) : 0.0f;
     p.id = id[i];
     pos[i] = p;
+    if (cellc) cellc[i] = pack_cell(cx, cy, cz);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Step lists.  The candidate lists carry a generous skin so that they survive several steps;  */
+/* a sweep only needs the candidates within the search radius plus what the particles move     */
+/* until the lists are drawn again.  Once per step (after the first sweep, on the positions the  */
+/* other seven start from, which differ from each other by dt^2-sized corrections) and after     */
+/* every rebuild, k_draw_lists copies out of every candidate row the entries within               */
+/* r_in = R*(1+margin), in the row's order; the pair kernel walks those.  Membership is still      */
+/* decided exactly by the pair kernel: the draw only has to keep every pair within r_in, so it      */
+/* works on 16-byte single-precision entries: the particle's place relative to the low corner of    */
+/* the cell it was in at the last rebuild (formed in double, rounded once) and that cell.          */
+struct __attribute__((aligned(16))) DPos {
+    float u, v, w;
+    uint32_t cell;
+};
+__global__ __launch_bounds__(SPH_BLOCK) void k_fill_dpos(const Rec* __restrict__ rec, const uint32_t* __restrict__ cellc,
+                                                         uint32_t m, GridParams g, int dim, DPos* __restrict__ dpos) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t cc = cellc[i];
+    const double edge = 1.0 / g.inv[0]; /* all axes share one edge */
+    DPos p;
+    p.u = (float)((rec[i].xv[0][0] - g.lo[0]) - (double)(cc & 4095u) * edge);
+    p.v = (float)((rec[i].xv[1][0] - g.lo[1]) - (double)((cc >> 12) & 1023u) * edge);
+    p.w = dim == 3 ? (float)((rec[i].xv[2][0] - g.lo[2]) - (double)(cc >> 22) * edge) : 0.0f;
+    p.cell = cc;
+    dpos[i] = p;
+}
+
+/* Four lanes per particle; the quad takes sixteen entries of the candidate row per step: one
+ * 16-byte read per lane, then four rounds in which the quad's lanes take four CONSECUTIVE
+ * entries (consecutive entries of a row are mostly consecutive particles: the four 16-byte
+ * gathers of a quad then fall into one 64-byte segment, and the vector-memory pipe is paced by
+ * the distinct segments an instruction touches).  Keepers are appended in the row's order. */
+template <int DIM>
+__global__ __launch_bounds__(SPH_BLOCK) void k_draw_lists(const DPos* __restrict__ dpos, uint32_t n,
+                                                          const uint32_t* __restrict__ nbr, uint32_t stride,
+                                                          const uint32_t* __restrict__ cnt, float edge, float r2f,
+                                                          uint32_t* __restrict__ nbr_out, uint32_t* __restrict__ cnt_out,
+                                                          DevScalars* __restrict__ S) {
+    /* the lists drawn here start their own travel bound */
+    if (blockIdx.x == 0 && threadIdx.x == 0) S->disp_in = 0.0;
+    const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
+    const uint32_t i_raw = xcd_contiguous_block() * (SPH_BLOCK / 4) + (threadIdx.x >> 2);
+    const bool active = i_raw < n;
+    const uint32_t i = active ? i_raw : n - 1;
+    const DPos pi = dpos[i];
+    const uint32_t c = active ? cnt[i] : 0u;
+    const int cxi = (int)(pi.cell & 4095u), cyi = (int)((pi.cell >> 12) & 1023u), czi = (int)(pi.cell >> 22);
+    const uint32_t* const row = nbr + (size_t)i * stride;
+    uint32_t* const out = nbr_out + (size_t)i * stride;
+    const uint32_t last_group = stride - 4u;
+    const uint32_t below = (1u << q) - 1u;
+    uint32_t k = 0;
+    for (uint32_t e0 = 0; e0 < c; e0 += 16u) {
+        const uint32_t eg = e0 + 4u * q;
+        const u32x4_t v = *(const u32x4_t*)(row + (eg < last_group ? eg : last_group));
+        uint32_t j[4];
+        DPos pj[4];
+        /* round m: the group that lane m read, entry q of it to lane q */
+#define DRAW_PICK(M)                                                          \
+    {                                                                         \
+        const uint32_t a0 = (uint32_t)quad_perm_i<(M)*0x55>((int)v.x);        \
+        const uint32_t a1 = (uint32_t)quad_perm_i<(M)*0x55>((int)v.y);        \
+        const uint32_t a2 = (uint32_t)quad_perm_i<(M)*0x55>((int)v.z);        \
+        const uint32_t a3 = (uint32_t)quad_perm_i<(M)*0x55>((int)v.w);        \
+        j[M] = q == 0 ? a0 : (q == 1 ? a1 : (q == 2 ? a2 : a3));              \
+        pj[M] = dpos[e0 + 4u * (M) + q < c ? j[M] : i];                       \
+    }
+        DRAW_PICK(0) DRAW_PICK(1) DRAW_PICK(2) DRAW_PICK(3)
+#undef DRAW_PICK
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int cxj = (int)(pj[m].cell & 4095u), cyj = (int)((pj[m].cell >> 12) & 1023u), czj = (int)(pj[m].cell >> 22);
+            const float dx = (float)(cxj - cxi) * edge + (pj[m].u - pi.u);
+            const float dy = (float)(cyj - cyi) * edge + (pj[m].v - pi.v);
+            const float dz = DIM == 3 ? (float)(czj - czi) * edge + (pj[m].w - pi.w) : 0.0f;
+            const bool keep = e0 + 4u * m + q < c && dx * dx + dy * dy + dz * dz <= r2f;
+            const uint32_t bits = (uint32_t)(__ballot(keep) >> (lane & 60u)) & 0xFu;
+            if (keep) out[k + __popc(bits & below)] = j[m];
+            k += __popc(bits);
+        }
+    }
+    if (active && q == 0) cnt_out[i] = k;
 }
 
 /* Four lanes per particle: the quad walks each neighbouring cell four candidates at a time and
@@ -424,7 +566,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
                                                           uint32_t wall_below, const uint32_t* __restrict__ hbeg,
                                                           const uint32_t* __restrict__ hend) {
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
-    const uint32_t i_raw = blockIdx.x * (SPH_BLOCK / 4) + (threadIdx.x >> 2);
+    const uint32_t i_raw = xcd_contiguous_block() * (SPH_BLOCK / 4) + (threadIdx.x >> 2);
     const bool active = i_raw < n;
     const uint32_t i = active ? i_raw : n - 1;
     /* wall_below > 0: pairs of two wall particles are left out (see k_walls_at_rest) */
@@ -432,7 +574,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
     const bool i_wall = pi.id < wall_below;
     const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
     const float edge = (float)(1.0 / g.inv[0]); /* all axes share one edge */
-    const float rl2f = (float)(rl2 * (1.0 + LIST_FLOAT_MARGIN));
+    const float rl2f = (float)(rl2 * (1.0 + list_float_margin(1.0 / g.inv[0], sqrt(rl2))));
     const int cx = cell_coord(xi, g.lo[0], g.inv[0], g.n[0]);
     const int cy = cell_coord(yi, g.lo[1], g.inv[1], g.n[1]);
     const int cz = DIM == 3 ? cell_coord(zi, g.lo[2], g.inv[2], g.n[2]) : 0;
@@ -543,31 +685,6 @@ __device__ __forceinline__ double tait_pow_m1(double x, double gam) {
     return pow(x, gam) - 1.0;
 }
 
-/* data-parallel-primitive moves inside a quad of lanes: CTRL is a quad_perm pattern */
-template <int CTRL>
-__device__ __forceinline__ int quad_perm_i(int v) {
-    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
-}
-template <int CTRL>
-__device__ __forceinline__ double quad_perm_d(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = quad_perm_i<CTRL>((int)(b & 0xFFFFFFFFll));
-    const int hi = quad_perm_i<CTRL>((int)(b >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-#define QP_XOR1 0xB1 /* lanes [1,0,3,2] */
-#define QP_XOR2 0x4E /* lanes [2,3,0,1] */
-__device__ __forceinline__ double quad_sum(double v) {
-    v += quad_perm_d<QP_XOR1>(v);
-    v += quad_perm_d<QP_XOR2>(v);
-    return v;
-}
-__device__ __forceinline__ double quad_max(double v) {
-    v = fmax(v, quad_perm_d<QP_XOR1>(v));
-    v = fmax(v, quad_perm_d<QP_XOR2>(v));
-    return v;
-}
-
 /* 1/x for a normal positive x, to about one unit in the last place: the hardware estimate
  * plus two Newton steps. */
 __device__ __forceinline__ double fast_rcp(double x) {
@@ -603,8 +720,6 @@ __device__ __forceinline__ double fast_sqrt(double x) {
 
 /* Streamed-once data (candidate rows, state n, everything written) is moved with the
  * non-temporal hint, so that the L2 keeps what is reused: the neighbour records. */
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef double f64x2_t __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ __forceinline__ T stream_load(const T* p) {
 #ifdef SPH_NT_LOADS
@@ -667,12 +782,8 @@ __device__ unsigned long long g_phase[8];
  *  FUSED: the quad then performs the wall reset, the Newmark-beta update, the Tait pressure
  *  and the position-change sum for its particle (WCXSPH3D.cpp:260-285): lane d owns
  *  component d (and writes chunk d of the new record), lane 3 owns rho, p and Rrho.
- *
- *  FILTER: the step's working list.  Candidate lists carry a generous skin so that they
- *  survive many steps; within one step particles move a small fraction of it.  The first
- *  sweep of a step, which tests every candidate anyway, writes out those within a tighter
- *  radius (same order); the other sweeps walk that shorter list. */
-template <int DIM, bool XSPH, bool FUSED, bool FILTER, bool WIDE>
+ */
+template <int DIM, bool XSPH, bool FUSED, bool WIDE>
 __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, const Rec* __restrict__ rin,
                                                     const uint32_t* __restrict__ nbr, uint32_t stride,
                                                     const uint32_t* __restrict__ cnt, OutState out, int store_out,
@@ -680,8 +791,7 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
                                                     Rec* __restrict__ rout, float* __restrict__ pout,
                                                     DevScalars* __restrict__ S, double* __restrict__ part,
                                                     uint32_t first, uint32_t count, uint32_t part_base,
-                                                    uint32_t part_n, uint32_t* __restrict__ nbr_out,
-                                                    uint32_t* __restrict__ cnt_out, double r_in2) {
+                                                    uint32_t part_n) {
     __shared__ __attribute__((aligned(16))) char stage[(PAIR_BLOCK / 64) * PAIR_LDS_WAVE];
     PHASE_MARK(0)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -690,8 +800,7 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
      * XCD one contiguous eighth of the cell-ordered particles, so that the records a
      * workgroup gathers are the ones its neighbours on the same L2 have just fetched.
      * (Placement only changes speed, never results.) */
-    const uint32_t per_xcd = gridDim.x >> 3; /* the grid is a multiple of 8 */
-    const uint32_t block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t block = xcd_contiguous_block(); /* the grid is a multiple of 8 */
     /* this launch covers particles [first, first+count) (a slab run launches its boundary
      * layers and its interior separately) */
     const uint32_t i_raw = first + block * PAIR_PARTICLES + (threadIdx.x >> 2);
@@ -755,8 +864,6 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
 
     /* the four pieces this lane holds of the next round's records */
     uint4 pc0, pc1, pc2, pc3;
-    uint32_t jnext = 0, kept = 0; /* FILTER: this lane's candidate of the round in flight; entries written */
-    uint32_t* const row_out = FILTER ? nbr_out + (size_t)i * stride : nullptr;
     /* While the record array is smaller than 4 GiB (!WIDE) a 32-bit byte offset from its base
      * addresses any piece: one shift-or per load instead of 64-bit arithmetic. */
     const uint32_t qoff = 16u * (uint32_t)q;
@@ -777,7 +884,6 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
     /* load round t, whose four candidates sit in lane (t & 3) of the quad */
 #define LOAD_FROM(VEC, R, T)                                                        \
     {                                                                               \
-        const uint32_t e0 = (T) * 4u;                                               \
         const uint32_t a0 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).x);           \
         const uint32_t a1 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).y);           \
         const uint32_t a2 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).z);           \
@@ -785,7 +891,6 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
         /* entries past the count are stale or zero but always index the arrays (the lists are  \
          * cleared when allocated); what is fetched for them is never used */                   \
         load4(a0, a1, a2, a3);                                                                  \
-        if (FILTER) jnext = q == 0 ? a0 : (q == 1 ? a1 : (q == 2 ? a2 : a3));      \
     }
     char* const my_slot = wstage + lane * 16;
     auto exchange = [&]() -> Rec {
@@ -803,17 +908,11 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
 
     const int my_limit = (int)c - q; /* lane q holds entry 4t+q of round t: valid while 4t < c-q */
     uint32_t hits = 0;               /* wave total, kept on the scalar side */
-    auto pair_term = [&](uint32_t t, const Rec& rj, uint32_t j) {
+    auto pair_term = [&](uint32_t t, const Rec& rj) {
         const bool valid = (int)(t * 4u) < my_limit;
         const double Rx = rj.xv[0][0] - xi0, Ry = rj.xv[1][0] - xi1;
         const double Rz = DIM == 3 ? rj.xv[2][0] - xi2 : 0.0;
         const double d2 = dist2_exact(Rx, Ry, Rz);
-        if (FILTER) { /* the quad appends its keepers in lane order */
-            const bool keep = valid && d2 <= r_in2;
-            const uint32_t bits = (uint32_t)(__ballot(keep) >> (lane & 60)) & 0xFu;
-            if (keep) stream_store(row_out + kept + __popc(bits & ((1u << q) - 1u)), j);
-            kept += __popc(bits);
-        }
         const bool hit = valid && d2 < P.R2;
         hits += (uint32_t)__popcll(__ballot(hit));
         if (hit) {
@@ -872,9 +971,8 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
         const uint32_t t = u * 4u + (R);                       \
         if (t >= rounds) break;                                \
         const Rec rj = exchange();                             \
-        const uint32_t jcur = jnext;                           \
         if (t + 1 < rounds) LOAD_FROM(NEXTVEC, NEXTR, t + 1)   \
-        pair_term(t, rj, jcur);                                \
+        pair_term(t, rj);                                      \
     }
 
     PHASE_MARK(1)
@@ -899,8 +997,6 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
 #undef ROUND
 #undef LOAD_FROM
     PHASE_MARK(2)
-
-    if (FILTER && active && q == 0) cnt_out[i] = kept;
 
     /* quad totals */
     acc0 = quad_sum(acc0); acc1 = quad_sum(acc1);
@@ -1081,10 +1177,18 @@ __global__ void k_forces_finalize(DevScalars* S, const double* __restrict__ part
 /* Start of a Newmark_Beta call. */
 __global__ void k_step_begin(DevScalars* S) { S->violation = 0; }
 
-/* End of sweep k: errsum, logbase, the travel bound that guards the candidate lists, and
- * after the last sweep the new time step (WCXSPH3D.cpp:280-288, 293-298). */
+/* End of sweep k: errsum, logbase, the travel bounds that guard the lists, and after the last
+ * sweep the new time step (WCXSPH3D.cpp:280-288, 293-298).
+ *
+ * The positions just written feed the next sweep's pair loop through lists built earlier.  A
+ * list drawn with radius r' > R is complete for the search radius R while no particle has
+ * travelled more than (r' - R)/2 since it was drawn.  Two bounds are kept: disp since the
+ * candidate lists were built, disp_in since the step lists were drawn (by the step's second
+ * sweep, from the candidates).  cand_limit >= 0: the next sweep walks the candidate lists and
+ * needs disp <= cand_limit.  check_in: the next sweep walks the step lists and needs
+ * disp_in <= limit_in.  reset_in: the next sweep draws the step lists, their bound starts at 0. */
 __global__ void k_sweep_finalize(DevParams P, DevScalars* S, const double* __restrict__ part2, int k, int last,
-                                 int guard_lists) {
+                                 double cand_limit, int check_in, int reset_in) {
     const double maxmu = fold_groups(part2, 0);
     const double maxf2 = fold_groups(part2, 1);
     const double move2 = fold_groups(part2, 2);
@@ -1096,13 +1200,12 @@ __global__ void k_sweep_finalize(DevParams P, DevScalars* S, const double* __res
         S->logbase = log10(sqrt(errsum / P.npts_d));
     }
     S->maxmu = maxmu;
-    S->disp += sqrt(move2);
-    S->disp_in += sqrt(move2);
-    /* the positions just written feed the next sweep's pair loop through lists built earlier:
-     * they are only complete while no particle has travelled more than half the skin of the
-     * list in use (1: the candidate lists, 2: the step's working lists) */
-    if (guard_lists == 1 && !last && !(S->disp <= S->disp_limit)) S->violation = 1;
-    if (guard_lists == 2 && !last && !(S->disp_in <= S->limit_in)) S->violation = 1;
+    const double move = sqrt(move2);
+    S->disp += move;
+    const double din = reset_in ? 0.0 : S->disp_in + move;
+    S->disp_in = din;
+    if (!last && cand_limit >= 0.0 && !(S->disp <= cand_limit)) S->violation = 1;
+    if (!last && check_in && !(din <= S->limit_in)) S->violation = 1;
     if (last) {
         const double maxf = sqrt(maxf2);
         S->maxf = maxf;

@@ -272,30 +272,33 @@ def gather_state(sim, state, dist, group=None):
 
 
 # ---------------------------------------------------------------------------------------------
-# multi-GPU benchmark (weak scaling: the fluid block and the box grow along x with the ranks)
+# multi-GPU benchmark: weak scaling (the fluid block and the box grow along x with the ranks) or
+# strong scaling (one fixed case cut into as many slabs as there are ranks)
 
 
 def bench_main(args, world, rank, local_rank, fluid):
+    import threading
+
     import torch
     import torch.distributed as dist
     import bench as B
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     # a transport that never returns must not hold the node for ever: give up loudly
-    import threading
+    limit_s = int(os.environ.get("SPH_BENCH_LIMIT_S", "1500"))
 
     def give_up():
         print("rank %d: bench did not finish within %d s, giving up" % (rank, limit_s), file=sys.stderr, flush=True)
         os._exit(3)
 
-    limit_s = int(os.environ.get("SPH_BENCH_LIMIT_S", "900"))
     watchdog = threading.Timer(limit_s, give_up)
     watchdog.daemon = True
     watchdog.start()
     # control plane (id broadcast, barriers, timing) on gloo; particle data moves over RCCL
     dist.init_process_group("gloo", rank=rank, world_size=world)
     nx, ny, nz = fluid
-    case = B.dam_break_3d(nx * world, ny, nz)
+    strong = args.scaling == "strong"
+    case = B.dam_break_3d(nx if strong else nx * world, ny, nz)
     t_setup = time.perf_counter()
 
     def all_ok(err):
@@ -310,16 +313,19 @@ def bench_main(args, world, rank, local_rank, fluid):
 
     sim, err = None, None
     try:
-        sim = SlabSim.from_case(case, rank, world, device=local_rank)
+        sim = SlabSim.from_case(case, rank, world, device=local_rank, skin_frac=args.skin, inner_skin_frac=args.inner)
     except Exception as e:  # reported below, on every rank
         err = repr(e)
     all_ok(err)
-    transport = os.environ.get("SPH_TRANSPORT", "rccl")
-    if transport == "rccl":
+    asked = os.environ.get("SPH_TRANSPORT", "rccl")
+    if asked not in ("rccl", "host"):
+        raise SystemExit("SPH_TRANSPORT must be rccl or host")
+    transport, why_not_rccl, rccl_thread = asked, None, None
+    if asked == "rccl":
         ident = [capi.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
         # creating the communicator is a collective inside RCCL: if it does not return, every
-        # rank gives up after the same time and the run goes on over the staged transport
+        # rank gives up after the same time
         got = {}
 
         def create():
@@ -329,78 +335,72 @@ def bench_main(args, world, rank, local_rank, fluid):
                 got["why"] = str(e)
 
         wait_s = float(os.environ.get("SPH_RCCL_INIT_S", "120"))
-        th = threading.Thread(target=create, daemon=True)
-        th.start()
-        th.join(wait_s)
+        rccl_thread = threading.Thread(target=create, daemon=True)
+        rccl_thread.start()
+        rccl_thread.join(wait_s)
         why = got.get("why")
-        if th.is_alive():
+        if rccl_thread.is_alive():
             why = "ncclCommInitRank did not return within %.0f s" % wait_s
         failed = torch.tensor([1 if why else 0], dtype=torch.int32)
         dist.all_reduce(failed, op=dist.ReduceOp.MAX)
         if int(failed[0]):
-            # no communicator (e.g. ranks sharing a GPU): every rank moves to the staged transport
-            if why and rank == 0:
-                print("RCCL transport unavailable (%s); halo bytes staged through the host" % why, file=sys.stderr, flush=True)
+            # no communicator (e.g. ranks sharing a GPU).  The run goes on over the staged transport
+            # so that there is a line to read, says so in `transport`, and ends with a failure code.
+            why_not_rccl = why or "another rank could not create the communicator"
+            if rank == 0:
+                print("RCCL transport unavailable (%s); halo bytes staged through the host, exit code 4"
+                      % why_not_rccl, file=sys.stderr, flush=True)
             transport = "host"
-    if transport == "rccl":
-        pass
-    elif transport == "host":  # ranks sharing a GPU on a development box: staged through gloo
+    if transport == "host":  # ranks sharing a GPU on a development box: staged through gloo
         host_tr = HostTransport(rank, world)
         sim.set_transport(host_tr.struct)
-    else:
-        raise SystemExit("SPH_TRANSPORT must be rccl or host")
     sim.forces(capi.STATE_N)
     sim.zero_boundary_forces(capi.STATE_N)
     setup_s = time.perf_counter() - t_setup
-
-    for _ in range(args.warmup):
-        sim.step(1)
     all_ok(None)
-    sim.profile_enable(True)
-    sim.profile_read()
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    sc = sim.step(args.steps)
-    torch.cuda.synchronize()
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
-    prof = sim.profile_read()
-    t = torch.tensor([elapsed, prof["pair_ms"] / max(prof["pair_launches"], 1)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    counts = torch.tensor([sim.npts], dtype=torch.int64)
-    allc = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(allc, counts)
-    elapsed, pair_ms = float(t[0]), float(t[1])
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    def agree_max(vals):
+        t = torch.tensor(vals, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    rest, dev, reinit_ms = B.Legs(sim, args, sync, agree_max).run()
+    sent, recvd = sim.halo_counts()
+    info = torch.tensor([sim.npts, sent[0] + sent[1]], dtype=torch.int64)
+    alli = [torch.zeros_like(info) for _ in range(world)]
+    dist.all_gather(alli, info)
     n = sim.npts_global
     if rank == 0:
-        value = n * args.steps / elapsed
-        per = [int(c[0]) for c in allc]
-        b_alg = (B.B_ALG_PAIR + B.B_ALG_UPDATE) * max(per)
-        ach = b_alg / (pair_ms * 1e-3) / 1e9
-        out = {
-            "metric": "particle-steps/sec (3-D WCXSPH dam break)",
-            "value": value, "unit": "particle-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {
-                "workload": "C3 x %d along x: WCXSPH3D dam break, Pstep 0.1, fluid %dx%dx%d + walls, "
-                            "box %.1fx%.1fx%.1f, %d x-slabs, halo exchange over %s"
-                            % (world, nx * world, ny, nz, case.box[0], case.box[1], case.box[2], world,
-                               "RCCL send/recv" if transport == "rccl" else "host staging + gloo"),
-                "particles": n, "particles_per_rank": per, "sweeps_per_step": 8, "force_evals_per_s": value * 8,
-                "list_rebuilds": prof["rebuilds"], "step_redos": sc["step_redos"], "setup_s": setup_s,
-            },
-            "roofline": {
-                "kernel": "k_pair<3,xsph,fused>, the three launches of one sweep (two boundary layers + interior), slowest rank",
-                "bound": "hbm", "achieved": ach, "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / B.HBM_PEAK_GBS, "traffic": None, "kernel_ms": pair_ms,
-            },
-        }
+        per = [int(c[0]) for c in alli]
+        halo = [int(c[1]) for c in alli]
+        how = "RCCL send/recv" if transport == "rccl" else "host staging + gloo"
+        if strong:
+            workload = ("C4 cut into %d x-slabs (strong scaling)" if fluid == B.C4 else "custom size cut into %d x-slabs (strong scaling)") % world
+        else:
+            workload = "C3 x %d along x (weak scaling)" % world
+        workload += (": WCXSPH3D dam break, Pstep 0.1, fluid %dx%dx%d + walls, box %.1fx%.1fx%.1f, developed flow, halo exchange over %s"
+                     % (case.npart[0], ny, nz, case.box[0], case.box[1], case.box[2], how))
+        out = B.result_line(args, world, n, max(per), workload, rest, dev, reinit_ms, args.scaling, {
+            "particles_per_rank": per, "halo_particles_sent_per_rank": halo,
+            "halo_bytes_per_sweep_per_rank": [64 * h for h in halo], "setup_s": setup_s,
+        })
+        out["transport"] = transport
+        if why_not_rccl:
+            out["transport_note"] = "RCCL was asked for and could not be created: " + why_not_rccl
+        out["roofline"]["kernel"] = ("k_pair<3,xsph,fused>, the three launches of one sweep (two boundary layers + interior), "
+                                     "slowest rank")
         print(json.dumps(out), flush=True)
+    if rccl_thread is not None and rccl_thread.is_alive():
+        # the thread is still inside ncclCommInitRank with this context: leave the context alone
+        dist.barrier()
+        os._exit(4)
     sim.close()
     dist.barrier()
     dist.destroy_process_group()
     watchdog.cancel()
+    if why_not_rccl:
+        raise SystemExit(4)

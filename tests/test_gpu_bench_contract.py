@@ -23,21 +23,23 @@ def _port():
     return p
 
 
-def _check(line, n_gpus, steps, warmup):
+def _check(line, n_gpus, steps, warmup, scaling="weak"):
     d = json.loads(line)
     assert KEYS <= set(d), KEYS - set(d)
     assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
-    assert d["unit"] == "particle-steps/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "particle-steps/s" and d["higher_is_better"] is True and d["scaling"] == scaling
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    rest = d["config"]["at_rest"]
+    assert rest["value"] > 0 and d["config"]["reinit_ms"] > 0 and d["config"]["frame"]["ms"] > 10 * d["ms_per_step"]
     assert d["value"] > 0 and abs(d["value"] - d["config"]["particles"] * steps / (d["ms_per_step"] * steps * 1e-3)) <= 1e-6 * d["value"]
     return d
 
 
 def test_single_gpu_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--fluid", "48x24x12", "--steps", "2", "--warmup", "1"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--fluid", "48x24x12", "--steps", "2", "--warmup", "1", "--preroll", "40"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -48,14 +50,35 @@ def test_single_gpu_line():
     assert d["roofline"]["traffic"] is None  # counters were taken on the full-size workload only
 
 
-def test_two_rank_line():
-    env = dict(os.environ, SPH_TRANSPORT="host")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--fluid", "48x24x12", "--steps", "2", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+def _two_ranks(extra, env):
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, "bench.py"),
+                           "--gpus", "2", "--steps", "2", "--warmup", "1", "--preroll", "40"] + extra,
+                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+
+
+@pytest.mark.parametrize("scaling,fluid", [("weak", "48x24x12"), ("strong", "96x24x12")])
+def test_two_rank_line(scaling, fluid):
+    r = _two_ranks(["--fluid", fluid, "--scaling", scaling], dict(os.environ, SPH_TRANSPORT="host"))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
-    d = _check(lines[0], 2, 2, 1)
-    assert len(d["config"]["particles_per_rank"]) == 2 and sum(d["config"]["particles_per_rank"]) == d["config"]["particles"]
+    d = _check(lines[0], 2, 2, 1, scaling)
+    assert d["transport"] == "host"
+    per = d["config"]["particles_per_rank"]
+    assert len(per) == 2 and sum(per) == d["config"]["particles"]
+    assert all(h > 0 for h in d["config"]["halo_bytes_per_sweep_per_rank"])
+    # both modes ran the same whole case here: 96x24x12 in all
+    assert "96x24x12" in d["config"]["workload"]
+
+
+def test_two_ranks_without_rccl_say_so_and_fail():
+    # RCCL refuses two ranks on one GPU: the line is still printed, over the staged transport,
+    # marked as such, and the run ends with a failure code
+    env = {k: v for k, v in os.environ.items() if k != "SPH_TRANSPORT"}
+    r = _two_ranks(["--fluid", "48x24x12"], env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode != 0
+    assert len(lines) == 1, r.stdout + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["transport"] == "host" and "RCCL" in d["transport_note"]

@@ -380,11 +380,12 @@ def test_density_reinit_on_a_uniform_lattice_keeps_rho0_inside():
     sim.close()
 
 
-# ---- per-step working lists (opt-in knob) --------------------------------------------------------
+# ---- step lists (the second sweep of a step draws them from the candidates) ----------------------
 
 @pytest.mark.parametrize("name", ["wcxsph3d_block", "wcxsph_fine", "wcsph_fine"])
 def test_working_lists_give_the_same_answer(name):
-    # the first sweep of each step writes the candidates within 1.025 R; the rest walk those
+    # the second sweep of each step writes the candidates within 1.025 R; the later sweeps and the
+    # next step's first sweep walk those
     orc, sim = start(CASES[name], inner_skin_frac=0.025)
     orc.step(10)
     sc = sim.step(10)
@@ -394,8 +395,9 @@ def test_working_lists_give_the_same_answer(name):
 
 
 def test_working_lists_too_tight_fall_back_to_the_candidates():
-    # a margin far smaller than a step's motion: every step is redone on the full lists
-    orc, sim = start(CASES["wcxsph3d_block"], inner_skin_frac=1e-7)
+    # a margin far smaller than the motion between a step's sweeps: every step is redone on the
+    # full lists
+    orc, sim = start(CASES["wcxsph3d_block"], inner_skin_frac=1e-13)
     orc.step(30)
     sim.step(29)
     before = sim.scalars()["step_redos"]
@@ -403,6 +405,31 @@ def test_working_lists_too_tight_fall_back_to_the_candidates():
     assert sc["step_redos"] > before > 0
     assert_state_close(sim.download(capi.STATE_N), orc.get_state(O.STATE_N), "tight working lists")
     sim.close()
+
+
+def test_step_lists_change_nothing_but_roundings():
+    # rows of the step lists keep the candidates' order and only drop pairs outside the radius; the
+    # launch that draws them is a different instantiation of the kernel (its compiler may fuse
+    # multiply-adds differently), so fields agree to roundings, not bit for bit -- also with a wide
+    # skin and many rebuilds
+    spec = CASES["wcxsph3d_block"]
+    _, pc = util.both_cases(spec)
+    out = []
+    for inner in (-1.0, 0.01):
+        sim = capi.Sim.from_case(pc, skin_frac=0.3, inner_skin_frac=inner)
+        sim.forces(capi.STATE_N)
+        sim.zero_boundary_forces(capi.STATE_N)
+        sc = sim.step(40)
+        out.append((sc, sim.download(capi.STATE_NP1), sim.download(capi.STATE_N)))
+        sim.close()
+    (sa, pa, na), (sb, pb, nb) = out
+    assert sa["hit_pairs"] == sb["hit_pairs"] and sa["step_redos"] == sb["step_redos"] == 0
+    for k in ("dt", "t", "maxmu", "maxf", "errsum", "logbase"):
+        assert abs(sa[k] - sb[k]) <= 1e-11 * abs(sa[k]), k
+    for x, y in ((pa, pb), (na, nb)):
+        for k in ("x", "v", "V", "f"):
+            assert util.rel_err(x[k], y[k]) <= 1e-12, k
+        assert util.float_ulp_diff(x["rho"], y["rho"]).max() <= 1
 
 
 # ---- droplet / jet bodies (initialisers beyond the reference's box block) ------------------------

@@ -17,6 +17,7 @@ for target in [t for t in (20, 200, 600, 1200) if t <= last]:
     r0 = sim.scalars()
     t0 = time.perf_counter(); sc = sim.step(20); dt = time.perf_counter() - t0; done += 20
     pr = sim.profile_read()
-    print("steps %4d t %.4f dt %.2e: %.2f ms/step, %.3g particle-steps/s, pair %.3f ms, rebuilds %d (%.1f ms each), redos %d, pairs/particle %.1f"
-          % (done, sc["t"], sc["dt"], dt / 20 * 1e3, sim.npts * 20 / dt, pr["pair_ms"] / max(pr["pair_launches"], 1), pr["rebuilds"],
+    kinds = " ".join("%d x %.3f" % (n, m / max(n, 1)) for m, n in zip(pr["pair_ms_by_kind"], pr["pair_launches_by_kind"]))
+    print("steps %4d t %.4f dt %.2e: %.2f ms/step, %.3g particle-steps/s, pair %.3f ms [on candidates / on step lists / draws: %s], rebuilds %d (%.1f ms each), redos %d, pairs/particle %.1f"
+          % (done, sc["t"], sc["dt"], dt / 20 * 1e3, sim.npts * 20 / dt, pr["pair_ms"] / max(pr["pair_launches"], 1), kinds, pr["rebuilds"],
              pr["rebuild_ms"] / max(pr["rebuilds"], 1), sc["step_redos"] - r0["step_redos"], (sc["hit_pairs"] + sim.npts) / sim.npts), flush=True)
