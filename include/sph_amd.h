@@ -109,6 +109,9 @@ typedef struct sph_scalars {
     uint64_t list_rebuilds;   /* neighbour-candidate rebuilds so far */
     uint64_t step_redos;      /* steps repeated because a particle outran the skin */
     uint64_t hit_pairs;       /* i != j pairs inside the search radius in the last sweep */
+    uint64_t host_syncs;      /* times the host has waited for the device on the stepping path so
+                                 far, list rebuilds not counted (one per step on one GPU; one per
+                                 step over a device-buffer transport) */
 } sph_scalars;
 
 typedef struct sph_ctx sph_ctx;
@@ -199,6 +202,9 @@ typedef struct sph_transport {
                     const void* sendR, uint64_t nsendR, void* recvR, uint64_t nrecvR, void* stream);
     /* In-place all-reduce of n doubles over all ranks; op 0 = max, 1 = sum. */
     int (*allreduce)(void* user, double* vals, int32_t n, int32_t op, void* stream);
+    /* Optional (may be NULL: two allreduce calls are made instead).  The step's agreement in one
+     * exchange: maxvals[0..nmax) folded with max and sumvals[0..nsum) with a sum, in place. */
+    int (*allreduce_max_sum)(void* user, double* maxvals, int32_t nmax, double* sumvals, int32_t nsum, void* stream);
 } sph_transport;
 
 /* Installs the transport (copied).  Required before the first Forces/step when nranks > 1. */

@@ -53,7 +53,7 @@ class Fields(C.Structure):
 class Scalars(C.Structure):
     _fields_ = [("dt", C.c_double), ("t", C.c_float), ("maxmu", C.c_double), ("maxf", C.c_double),
                 ("errsum", C.c_double), ("logbase", C.c_double), ("list_rebuilds", C.c_uint64),
-                ("step_redos", C.c_uint64), ("hit_pairs", C.c_uint64)]
+                ("step_redos", C.c_uint64), ("hit_pairs", C.c_uint64), ("host_syncs", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -70,11 +70,13 @@ class Case(C.Structure):
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                          C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_void_p)
+ALLREDUCE2_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.c_int32,
+                           C.c_void_p)
 
 
 class Transport(C.Structure):
     _fields_ = [("user", C.c_void_p), ("host_buffers", C.c_int32), ("sendrecv", SENDRECV_FN),
-                ("allreduce", ALLREDUCE_FN)]
+                ("allreduce", ALLREDUCE_FN), ("allreduce_max_sum", ALLREDUCE2_FN)]
 
 
 class SphError(RuntimeError):

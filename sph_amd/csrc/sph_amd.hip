@@ -127,6 +127,7 @@ struct sph_ctx {
     uint64_t reinit_rounds = 0; /* slab runs: exchanges of the last density re-initialisation */
 
     uint64_t rebuilds = 0, redos = 0;
+    uint64_t host_syncs = 0; /* host waits for the device on the stepping path outside list rebuilds */
     bool uploaded_n = false, uploaded_np1 = false;
 
     /* slab decomposition */
@@ -369,6 +370,38 @@ int allreduce_host(sph_ctx* c, double* vals, int n, int op) {
         return fail(c, SPH_ECOMM, "transport allreduce failed");
     HIPCHK(hipMemcpyAsync(vals, c->red_dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->comm));
     HIPCHK(hipStreamSynchronize(c->comm));
+    return SPH_OK;
+}
+
+/* The step's agreement: red_dev[0..RED_NMAX) folded with max and the RED_NSUM values behind them
+ * with a sum, over all ranks, in place on the device and in the order of the compute stream.
+ * A device-buffer transport makes no host synchronisation here. */
+int allreduce_step_scalars(sph_ctx* c) {
+    double* const dmax = c->red_dev;
+    double* const dsum = c->red_dev + RED_NMAX;
+    if (!c->tr.host_buffers) {
+        if (c->tr.allreduce_max_sum) {
+            if (c->tr.allreduce_max_sum(c->tr.user, dmax, RED_NMAX, dsum, RED_NSUM, (void*)c->stream) != 0)
+                return fail(c, SPH_ECOMM, "transport allreduce failed");
+            return SPH_OK;
+        }
+        if (c->tr.allreduce(c->tr.user, dmax, RED_NMAX, 0, (void*)c->stream) != 0 ||
+            c->tr.allreduce(c->tr.user, dsum, RED_NSUM, 1, (void*)c->stream) != 0)
+            return fail(c, SPH_ECOMM, "transport allreduce failed");
+        return SPH_OK;
+    }
+    double* const h = (double*)c->h_send; /* pinned */
+    HIPCHK(hipMemcpyAsync(h, c->red_dev, sizeof(double) * (RED_NMAX + RED_NSUM), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    ++c->host_syncs;
+    if (c->tr.allreduce_max_sum) {
+        if (c->tr.allreduce_max_sum(c->tr.user, h, RED_NMAX, h + RED_NMAX, RED_NSUM, nullptr) != 0)
+            return fail(c, SPH_ECOMM, "transport allreduce failed");
+    } else if (c->tr.allreduce(c->tr.user, h, RED_NMAX, 0, nullptr) != 0 ||
+               c->tr.allreduce(c->tr.user, h + RED_NMAX, RED_NSUM, 1, nullptr) != 0) {
+        return fail(c, SPH_ECOMM, "transport allreduce failed");
+    }
+    HIPCHK(hipMemcpyAsync(c->red_dev, h, sizeof(double) * (RED_NMAX + RED_NSUM), hipMemcpyHostToDevice, c->stream));
     return SPH_OK;
 }
 
@@ -964,6 +997,7 @@ int pack_n_into(sph_ctx* c, Rec* dst) {
 int read_scalars(sph_ctx* c) {
     HIPCHK(hipMemcpyAsync(c->S_host, c->S, sizeof(DevScalars), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    ++c->host_syncs;
     return SPH_OK;
 }
 
@@ -979,6 +1013,7 @@ void fill_scalars(sph_ctx* c, sph_scalars* out) {
     out->list_rebuilds = c->rebuilds;
     out->step_redos = c->redos;
     out->hit_pairs = s.hit_pairs;
+    out->host_syncs = c->host_syncs;
 }
 
 /* One sweep's pair/update launches.  A single domain is one launch.  A slab first does the
@@ -1131,32 +1166,21 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
         a.nrho = c->nfl[F_RHO];
         a.np = c->nfl[F_P];
         a.nRrho = c->nfl[F_RRHO];
-        if (!c->dist && !partial) {
+        if (c->dist) {
+            /* the ranks agree on the maxima, the sums and on whether to redo the step -- one
+             * exchange, on the device, in stream order; the time step and the commit follow
+             * from the agreed values, and the host looks at the result once */
+            hipLaunchKernelGGL(k_pack_global, dim3(1), dim3(1), 0, c->stream, c->S, c->red_dev);
+            CHK(allreduce_step_scalars(c));
+            hipLaunchKernelGGL(k_apply_global, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->red_dev, partial ? 0 : 1);
+        }
+        if (!partial) {
             hipLaunchKernelGGL(k_commit, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, a, c->S);
             hipLaunchKernelGGL(k_commit_scalars, dim3(1), dim3(1), 0, c->stream, c->S);
         }
         HIPCHK(hipGetLastError());
         CHK(read_scalars(c));
-        double disp_in_seen = c->S_host->disp_in;
-        if (c->dist) {
-            /* the ranks agree on the maxima, the sums and on whether to redo the step; the
-             * time step and the commit follow from the agreed values */
-            DevScalars& s = *c->S_host;
-            double vmax[5] = {s.maxmu, s.maxf, (double)s.violation, s.disp, s.disp_in};
-            double vsum[3] = {s.errsum0, s.errsum, (double)s.hit_pairs};
-            CHK(allreduce_host(c, vmax, 5, 0));
-            CHK(allreduce_host(c, vsum, 3, 1));
-            hipLaunchKernelGGL(k_apply_global, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, vmax[0], vmax[1], vsum[0], vsum[1],
-                               vsum[2], vmax[2] != 0.0 ? 1 : 0, partial ? 0 : 1);
-            if (!partial) {
-                hipLaunchKernelGGL(k_commit, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, a, c->S);
-                hipLaunchKernelGGL(k_commit_scalars, dim3(1), dim3(1), 0, c->stream, c->S);
-            }
-            HIPCHK(hipGetLastError());
-            CHK(read_scalars(c));
-            c->S_host->disp = vmax[3];
-            disp_in_seen = vmax[4];
-        }
+        const double disp_in_seen = c->S_host->disp_in;
         c->disp_host = c->S_host->disp;
         c->step_lists_valid = false;
         if (c->S_host->violation && mode < 2) {
@@ -1965,6 +1989,16 @@ static int rccl_allreduce(void* user, double* vals, int32_t n, int32_t op, void*
                : 1;
 }
 
+static int rccl_allreduce_max_sum(void* user, double* maxvals, int32_t nmax, double* sumvals, int32_t nsum, void* stream) {
+    RcclState* r = (RcclState*)user;
+    hipStream_t st = (hipStream_t)stream;
+    bool ok = r->GroupStart() == ncclSuccess;
+    ok = ok && r->AllReduce(maxvals, maxvals, (size_t)nmax, ncclDouble, ncclMax, r->comm, st) == ncclSuccess;
+    ok = ok && r->AllReduce(sumvals, sumvals, (size_t)nsum, ncclDouble, ncclSum, r->comm, st) == ncclSuccess;
+    ok = (r->GroupEnd() == ncclSuccess) && ok;
+    return ok ? 0 : 1;
+}
+
 static void rccl_release(void* p) {
     RcclState* r = (RcclState*)p;
     if (r->comm && r->CommDestroy) (void)r->CommDestroy(r->comm);
@@ -2032,6 +2066,7 @@ int sph_use_rccl(sph_ctx* c, const void* unique_id_128) {
     t.host_buffers = 0;
     t.sendrecv = rccl_sendrecv;
     t.allreduce = rccl_allreduce;
+    t.allreduce_max_sum = rccl_allreduce_max_sum;
     c->tr = t;
     c->have_tr = true;
     return SPH_OK;

@@ -1451,15 +1451,33 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_unpack_mig(MigArgs a, const Mig* 
     a.gid[i] = g.gid;
 }
 
+/* Slab runs: what a rank contributes to the step's agreement.  red[0..4] are folded with max
+ * over the ranks (max mu, max |f|, redo flag, the two travel bounds), red[5..7] with a sum
+ * (the position-change sums of the first and the last sweep, the pair count). */
+#define RED_NMAX 5
+#define RED_NSUM 3
+__global__ void k_pack_global(const DevScalars* __restrict__ S, double* __restrict__ red) {
+    red[0] = S->maxmu;
+    red[1] = S->maxf;
+    red[2] = (double)S->violation;
+    red[3] = S->disp;
+    red[4] = S->disp_in;
+    red[5] = S->errsum0;
+    red[6] = S->errsum;
+    red[7] = (double)S->hit_pairs;
+}
+
 /* the step's scalars once every rank's values are folded: the same arithmetic as the last
  * k_sweep_finalize, on global maxima and sums (WCXSPH3D.cpp:280-288, 293-298) */
-__global__ void k_apply_global(DevParams P, DevScalars* S, double maxmu, double maxf, double errsum0, double errsum,
-                               double hits, int violation, int full_step) {
+__global__ void k_apply_global(DevParams P, DevScalars* S, const double* __restrict__ red, int full_step) {
+    const double maxmu = red[0], maxf = red[1];
     S->maxmu = maxmu;
-    S->errsum = errsum;
-    S->logbase = log10(sqrt(errsum0 / P.npts_d));
-    S->hit_pairs = (unsigned long long)hits;
-    S->violation = violation;
+    S->violation = red[2] != 0.0 ? 1 : 0;
+    S->disp = red[3];
+    S->disp_in = red[4];
+    S->errsum = red[6];
+    S->logbase = log10(sqrt(red[5] / P.npts_d));
+    S->hit_pairs = (unsigned long long)red[7];
     if (full_step) {
         S->maxf = maxf;
         const double dtf = sqrt(P.H / maxf);

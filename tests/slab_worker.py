@@ -91,7 +91,9 @@ def main():
             done += k
             sim.density_reinit()
     else:
+        syncs0 = sim.scalars()["host_syncs"]
         sc = sim.step(args.steps)
+        res["host_syncs_in_steps"] = np.array([sc["host_syncs"] - syncs0, args.steps])
     st = sim.download(capi.STATE_N)
     if args.reinit:
         st["np1_rho"] = sim.download(capi.STATE_NP1, names=("rho",))["rho"]

@@ -35,7 +35,7 @@ def test_struct_layouts_match_the_header():
     # sizes as a C compiler lays the header's structs out (natural alignment)
     assert C.sizeof(capi.Params) == 8 + 16 + 8 * 10 + 8 + 8 + 8 * 4 + 8 + 8 + 8 * 4 + 8 + 8
     assert C.sizeof(capi.Fields) == 8 * 16
-    assert C.sizeof(capi.Scalars) == 8 + 8 + 8 * 4 + 8 * 3
+    assert C.sizeof(capi.Scalars) == 8 + 8 + 8 * 4 + 8 * 4
     assert C.sizeof(capi.Case) == 16 + 8 + 24 + 24 + 8 + 32 + 8 + 8 + 24 + 8 + 24
 
 

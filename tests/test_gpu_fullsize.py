@@ -14,7 +14,10 @@ import os
 import numpy as np
 import pytest
 
+from oracle import oracle as O
 from sph_amd import capi
+
+import util
 
 pytestmark = pytest.mark.gpu
 
@@ -164,3 +167,49 @@ def test_wcsph_million_particles_known_answers_and_knob_independence():
         assert np.max(np.abs(ga[k] - gb[k])) <= 1e-10 * np.max(np.abs(ga[k])), k
     sim.close()
     other.close()
+
+
+# ---- the oracle at the configurations' real sizes (one step each: the oracle does ~65 k
+# ---- particle-steps/s in 3-D, ~150 k in 2-D) ---------------------------------------------------
+
+def _one_step_against_the_oracle(spec, what, min_particles):
+    oc, pc = util.both_cases(spec)
+    orc, sim = O.Oracle(oc), capi.Sim.from_case(pc)
+    assert sim.npts == orc.npts > min_particles
+    # neighbour sets of the initial state: bit-exact (the oracle's cell back-end)
+    go, gc = sim.neighbours(capi.STATE_N)
+    oo, occ = orc.neighbours(O.STATE_N)
+    assert np.array_equal(go, oo) and np.array_equal(gc, occ), what + ": neighbour sets"
+    for s_, which in ((orc, O.STATE_N), (sim, capi.STATE_N)):
+        s_.forces(which)
+    orc.zero_boundary_f(O.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    orc.step(1)
+    sc = sim.step(1)
+    g, o = sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1)
+    for k in ("x", "v", "V", "f"):
+        err = util.rel_err(g[k].T, o[k])
+        assert err <= 1e-10, "%s: field %s off by %.3e" % (what, k, err)
+    for k in ("rho", "p"):
+        assert util.float_ulp_diff(g[k], o[k]).max() <= 1, "%s: %s" % (what, k)
+    osc = orc.scalars()
+    for k in ("dt", "maxmu", "maxf"):
+        assert abs(sc[k] - osc[k]) <= 1e-12 * max(abs(osc[k]), 1e-300), "%s: %s" % (what, k)
+    # the sets after the step (particles have moved; the walls' neighbours are in)
+    go, gc = sim.neighbours(capi.STATE_NP1)
+    oo, occ = orc.neighbours(O.STATE_NP1)
+    assert np.array_equal(go, oo) and np.array_equal(gc, occ), what + ": neighbour sets after the step"
+    sim.close()
+    orc.close()
+
+
+def test_c2_wcsph_full_size_one_step_against_the_oracle():
+    pstep = 0.003
+    p, _ = capi.case_init(dam_break_2d())
+    spec = dict(program=0, npart=(833, 1267), pstep=pstep, box=(15.0, 8.0), start=(0.31, 0.31), dt0=0.3 * p.H / p.Cs)
+    _one_step_against_the_oracle(spec, "C2 (2-D WCSPH, 1.08 M)", 1_000_000)
+
+
+def test_3d_million_particle_block_one_step_against_the_oracle():
+    spec = dict(program=2, npart=(160, 96, 48), pstep=0.1, box=(32.3, 9.9, 9.6), start=(0.15, 0.15, 0.15))
+    _one_step_against_the_oracle(spec, "3-D WCXSPH3D block, ~1 M", 900_000)

@@ -373,10 +373,16 @@ def test_density_reinit_beyond_the_one_workgroup_size(spec):
 def test_density_reinit_on_a_uniform_lattice_keeps_rho0_inside():
     # known answer: MLS reproduces a constant field wherever the moment matrix is invertible
     _, pc = util.both_cases(CASES["wcxsph3d_block"])
+    for prog in (0, 1, 2):
+        sim = capi.Sim.from_case(capi.default_case(prog))
+        sim.density_reinit()
+        rho = sim.download(capi.STATE_NP1)["rho"]
+        assert np.max(np.abs(rho.astype(np.float64) - 1000.0)) <= 1e-3, prog
+        sim.close()
     sim = capi.Sim.from_case(pc)
     sim.density_reinit()
     rho = sim.download(capi.STATE_NP1)["rho"]
-    assert np.isfinite(rho).all()
+    assert np.max(np.abs(rho.astype(np.float64) - 1000.0)) <= 1e-3
     sim.close()
 
 

@@ -204,6 +204,15 @@ def test_medium_size_slabs_against_the_single_domain(nranks, tmp_path):
     sim.close()
 
 
+def test_medium_size_slabs_against_the_oracle(tmp_path):
+    # the same ~0.57 M-particle case on two slabs against the CPU oracle on the whole domain
+    spec = dict(program=2, npart=(160, 80, 24), pstep=0.1, box=(32.3, 8.3, 4.8), start=(0.15, 0.15, 0.15))
+    res = run_slabs(spec, 2, tmp_path, steps=3)
+    orc, f0, nb = oracle_run(spec, 3)
+    check(res, orc, f0, nb, "0.57 M particles on 2 slabs")
+    assert res["per_rank"].min() > 50_000
+
+
 @pytest.mark.parametrize("name,nranks,vx", [("wcxsph3d_block", 3, 0.8), ("wcxsph_fine", 2, 0.9)])
 def test_device_buffer_transport(name, nranks, vx, tmp_path):
     # the callbacks in the form the RCCL transport uses (device pointers plus a stream), with
@@ -213,6 +222,10 @@ def test_device_buffer_transport(name, nranks, vx, tmp_path):
     orc, f0, nb = oracle_run(spec, 12, vx=vx)
     check(res, orc, f0, nb, "%s on %d slabs, device-buffer transport" % (name, nranks))
     assert res["moved"][:, 1].sum() > 0
+    # over device buffers the step's agreement (one exchange of maxima and sums) stays on the
+    # device: the host waits once per step, redone steps aside (list rebuilds are not counted)
+    syncs, steps = res["host_syncs_in_steps"]
+    assert syncs <= 2 * (steps + res["scalars"][7]), (syncs, steps)
 
 
 # ---- DensityReinit across slabs ----------------------------------------------------------------
