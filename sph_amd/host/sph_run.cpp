@@ -31,12 +31,24 @@
  *   device N                 HIP device ordinal
  *   frame_stride K           write every K-th frame to the .plt     (default 1: all, as the reference)
  *   threads N                host threads that format a frame       (default: the machine's, at most 16)
+ *   transport rccl|host      several GPUs: how halo bytes travel     (default rccl; host = staged through
+ *                            this program's sockets, for ranks that share a GPU)
+ *   migrate 0|1              several GPUs: particles change owner as they cross a slab plane (default 1)
+ *
+ * Several GPUs: start one process per GPU with the rank, the number of ranks and the local rank
+ * in the environment (RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run sets them, or
+ * OMPI_COMM_WORLD_RANK / _SIZE / _LOCAL_RANK, or SLURM_PROCID / SLURM_NTASKS / SLURM_LOCALID) and
+ * the address of rank 0 in MASTER_ADDR, its port in SPH_WIRE_PORT (default MASTER_PORT + 1, or
+ * 29617).  The case is cut into x-slabs of equal weighted particle count; every rank sets up and
+ * steps its own slab; rank 0 gathers the rows of each written frame and writes the one .plt file.
  * The rows of a frame are formatted by several threads into memory and written in order, and the
  * file is written while the GPU computes the next frame; the bytes are the same as from the
  * reference's single `f1 << ... << std::endl` loop.
  */
 #include "../../include/sph_amd.h"
+#include "wire.h"
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -58,6 +70,8 @@ struct Settings {
     int program = SPH_PROGRAM_WCXSPH;
     int reinit = 1, device = -1;
     int frame_stride = 1, threads = 0;
+    int migrate = 1;
+    std::string transport = "rccl";
     bool have_npart = false, have_box = false, have_start = false;
     double dt = 0, psize = 0, rho_ref = 0, viscosity = 0, gravity = 0, cs = 0;
     double npart[3] = {0, 0, 0}, box[3] = {0, 0, 0}, start[3] = {0, 0, 0};
@@ -111,6 +125,11 @@ bool read_settings(const char* path, Settings& s) {
         else if (key == "device") ls >> s.device;
         else if (key == "frame_stride") { ls >> s.frame_stride; if (s.frame_stride < 1) s.frame_stride = 1; }
         else if (key == "threads") ls >> s.threads;
+        else if (key == "migrate") ls >> s.migrate;
+        else if (key == "transport") {
+            ls >> s.transport;
+            if (s.transport != "rccl" && s.transport != "host") { std::cerr << "Unknown transport " << s.transport << std::endl; return false; }
+        }
         else std::cout << "Note: unknown settings key '" << key << "' ignored." << std::endl;
     }
     return true;
@@ -187,7 +206,8 @@ size_t first_broken(const HostState& s, size_t lo, size_t hi) {
     return s.n;
 }
 
-void write_frame(const HostState& s, std::ofstream& fp, float t, uint64_t bound_parts, int program, int nthreads) {
+/* Returns false after the reference's NaN report (the caller stops the run from its main thread). */
+bool write_frame(const HostState& s, std::ofstream& fp, float t, uint64_t bound_parts, int program, int nthreads) {
     /* the reference stops at the first broken fluid row, after writing the rows before it */
     const size_t bad = first_broken(s, (size_t)bound_parts, s.n);
     const size_t stop = bad < s.n ? bad : s.n;
@@ -226,8 +246,82 @@ void write_frame(const HostState& s, std::ofstream& fp, float t, uint64_t bound_
             std::cerr << s.norm(s.v, i) << " " << s.norm(s.f, i) << " " << s.rho[i] << " " << s.p[i] << std::endl;
         }
         fp.close();
-        exit(-1);
+        return false;
     }
+    return true;
+}
+
+/* ---- several GPUs ------------------------------------------------------------------------- */
+
+int env_int(const char* const* names, int fallback) {
+    for (; *names; ++names)
+        if (const char* v = getenv(*names)) return atoi(v);
+    return fallback;
+}
+
+/* x-planes p[0] = -inf < ... < p[nranks] = +inf that give the slabs about equal work; a wall
+ * particle counts `wall_weight` of a fluid one (pairs of two resting wall particles are never
+ * evaluated) */
+bool choose_planes(const sph_case& cs, int nranks, std::vector<double>& planes, double wall_weight = 0.4, int nbins = 16384) {
+    std::vector<uint64_t> fl((size_t)nbins), wl((size_t)nbins);
+    if (sph_case_histogram_x(&cs, nbins, fl.data(), wl.data()) != SPH_OK) return false;
+    std::vector<double> cum((size_t)nbins);
+    double run = 0;
+    for (int b = 0; b < nbins; ++b) {
+        run += (double)fl[(size_t)b] + wall_weight * (double)wl[(size_t)b];
+        cum[(size_t)b] = run;
+    }
+    planes.assign(1, -1e300);
+    for (int r = 1; r < nranks; ++r) {
+        const double target = run * r / nranks;
+        int b = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        b = std::min(b + 1, nbins);
+        planes.push_back(cs.box[0] * (double)b / (double)nbins);
+    }
+    planes.push_back(1e300);
+    for (size_t k = 0; k + 1 < planes.size(); ++k)
+        if (!(planes[k + 1] > planes[k])) return false;
+    return true;
+}
+
+/* the host-staged transport of include/sph_amd.h over this program's sockets */
+int wire_sendrecv(void* user, const void* sL, uint64_t nsL, void* rL, uint64_t nrL, const void* sR, uint64_t nsR, void* rR,
+                  uint64_t nrR, void*) {
+    return ((Wire*)user)->sendrecv(sL, nsL, rL, nrL, sR, nsR, rR, nrR) ? 0 : 1;
+}
+int wire_allreduce(void* user, double* vals, int32_t n, int32_t op, void*) { return ((Wire*)user)->allreduce(vals, n, op) ? 0 : 1; }
+
+/* one rank's rows of a frame as they travel to rank 0: count, global indices, then the fields */
+void pack_rows(const HostState& s, const std::vector<uint32_t>& gids, std::vector<char>& out) {
+    const uint64_t n = s.n;
+    out.resize(8 + n * 4 + n * 8 * (size_t)(3 * s.dim) + n * 4 * 2);
+    char* p = out.data();
+    auto put = [&p](const void* src, size_t bytes) { memcpy(p, src, bytes); p += bytes; };
+    put(&n, 8);
+    put(gids.data(), n * 4);
+    for (int d = 0; d < s.dim; ++d) { put(s.x[d].data(), n * 8); put(s.v[d].data(), n * 8); put(s.f[d].data(), n * 8); }
+    put(s.rho.data(), n * 4);
+    put(s.p.data(), n * 4);
+}
+void unpack_rows(const char* p, int dim, HostState& whole) {
+    uint64_t n;
+    memcpy(&n, p, 8);
+    p += 8;
+    const uint32_t* g = (const uint32_t*)p;
+    p += n * 4;
+    for (int d = 0; d < dim; ++d) {
+        std::vector<double>* dst[3] = {&whole.x[d], &whole.v[d], &whole.f[d]};
+        for (int q = 0; q < 3; ++q) {
+            const double* src = (const double*)p;
+            for (uint64_t i = 0; i < n; ++i) (*dst[q])[g[i]] = src[i];
+            p += n * 8;
+        }
+    }
+    const float* r = (const float*)p;
+    for (uint64_t i = 0; i < n; ++i) whole.rho[g[i]] = r[i];
+    p += n * 4;
+    const float* pr = (const float*)p;
+    for (uint64_t i = 0; i < n; ++i) whole.p[g[i]] = pr[i];
 }
 
 void die(sph_ctx* ctx, const char* what) {
@@ -270,70 +364,206 @@ int main(int argc, char* argv[]) {
         std::cerr << "Invalid simulation definition." << std::endl;
         exit(-1);
     }
-    prm.device = st.device;
-    const uint64_t simpts = prm.npts - prm.bound_parts;
+    const uint64_t npts_all = prm.npts, bound_parts = prm.bound_parts;
+    const uint64_t simpts = npts_all - bound_parts;
 
-    /* InitSPH (WCXSPH3D.cpp:306-379) */
-    std::cout << "Initialising simulation with " << simpts << " particles" << std::endl;
+    /* one process per GPU: who am I (read before anything touches a GPU) */
+    static const char* const k_rank[] = {"RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID", nullptr};
+    static const char* const k_size[] = {"WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS", nullptr};
+    static const char* const k_local[] = {"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", nullptr};
+    const int rank = env_int(k_rank, 0), nranks = std::max(1, env_int(k_size, 1)), local_rank = env_int(k_local, 0);
+    const bool root = rank == 0, multi = nranks > 1;
+    Wire wire;
+    if (multi) {
+        static const char* const k_port[] = {"SPH_WIRE_PORT", nullptr};
+        static const char* const k_mport[] = {"MASTER_PORT", nullptr};
+        int port = env_int(k_port, 0);
+        if (port <= 0) port = env_int(k_mport, 29616) + 1;
+        const char* addr = getenv("MASTER_ADDR");
+        if (!wire.open(rank, nranks, addr ? addr : "127.0.0.1", port)) {
+            std::cerr << "rank " << rank << ": " << wire.error << std::endl;
+            exit(-1);
+        }
+    }
+    prm.device = st.device >= 0 ? st.device : (multi ? local_rank : -1);
+
+    /* InitSPH (WCXSPH3D.cpp:306-379): the whole case on one GPU, this rank's slab otherwise */
+    if (root) std::cout << "Initialising simulation with " << simpts << " particles" << std::endl;
     HostState hs, hs_alt; /* two sets: one is written to the file while the other is filled */
-    hs.resize(prm.dim, (size_t)prm.npts);
-    hs_alt.resize(prm.dim, (size_t)prm.npts);
-    sph_fields h = hs.fields();
+    HostState local;      /* several GPUs: this rank's rows */
+    std::vector<uint32_t> gids;
     int nthreads = st.threads > 0 ? st.threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (sph_case_init(&cs, &h) != SPH_OK) exit(-1);
-    std::cout << "Total Particles: " << prm.npts << std::endl;
+    if (root) {
+        hs.resize(prm.dim, (size_t)npts_all);
+        hs_alt.resize(prm.dim, (size_t)npts_all);
+    }
+    if (multi) {
+        std::vector<double> planes;
+        if (!choose_planes(cs, nranks, planes)) {
+            std::cerr << "Cannot cut " << nranks << " slabs out of this case." << std::endl;
+            exit(-1);
+        }
+        uint64_t n_own = 0;
+        if (sph_case_init_range(&cs, planes[(size_t)rank], planes[(size_t)rank + 1], nullptr, nullptr, &n_own) != SPH_OK || n_own == 0) {
+            std::cerr << "rank " << rank << " owns no particle" << std::endl;
+            exit(-1);
+        }
+        local.resize(prm.dim, (size_t)n_own);
+        gids.resize((size_t)n_own);
+        sph_fields hl = local.fields();
+        if (sph_case_init_range(&cs, planes[(size_t)rank], planes[(size_t)rank + 1], &hl, gids.data(), &n_own) != SPH_OK) exit(-1);
+        const uint64_t room = std::max<uint64_t>(1u << 16, n_own / 8);
+        prm.npts_global = npts_all;
+        prm.npts = n_own;
+        prm.rank = rank;
+        prm.nranks = nranks;
+        prm.capacity = n_own + 4 * room; /* growth by migration 2*room, each side's halo room */
+        prm.migrate = st.migrate ? 1 : 0;
+        prm.slab_lo = planes[(size_t)rank];
+        prm.slab_hi = planes[(size_t)rank + 1];
+    } else {
+        sph_fields h = hs.fields();
+        if (sph_case_init(&cs, &h) != SPH_OK) exit(-1);
+    }
+    if (root) std::cout << "Total Particles: " << npts_all << std::endl;
 
     sph_ctx* ctx = nullptr;
     if (sph_create(&prm, &ctx) != SPH_OK) die(ctx, "sph_create");
-    if (sph_upload(ctx, SPH_STATE_N, &h) != SPH_OK) die(ctx, "sph_upload");
-    if (sph_upload(ctx, SPH_STATE_NP1, &h) != SPH_OK) die(ctx, "sph_upload"); /* the particlesh copy, :450-451 */
+    {
+        sph_fields h = multi ? local.fields() : hs.fields();
+        if (sph_upload(ctx, SPH_STATE_N, &h) != SPH_OK) die(ctx, "sph_upload");
+        if (sph_upload(ctx, SPH_STATE_NP1, &h) != SPH_OK) die(ctx, "sph_upload"); /* the particlesh copy, :450-451 */
+    }
+    sph_transport wire_tr;
+    if (multi) {
+        if (sph_upload_global_ids(ctx, gids.data()) != SPH_OK) die(ctx, "sph_upload_global_ids");
+        if (st.transport == "rccl") {
+            char id[128];
+            memset(id, 0, sizeof id);
+            if (root && sph_rccl_unique_id(id) != SPH_OK) {
+                std::cerr << "sph_rccl_unique_id failed (is librccl.so.1 on the loader path?)" << std::endl;
+                exit(-1);
+            }
+            if (!wire.bcast(id, sizeof id)) { std::cerr << wire.error << std::endl; exit(-1); }
+            if (sph_use_rccl(ctx, id) != SPH_OK) die(ctx, "sph_use_rccl");
+        } else {
+            memset(&wire_tr, 0, sizeof wire_tr);
+            wire_tr.user = &wire;
+            wire_tr.host_buffers = 1;
+            wire_tr.sendrecv = wire_sendrecv;
+            wire_tr.allreduce = wire_allreduce;
+            if (sph_set_transport(ctx, &wire_tr) != SPH_OK) die(ctx, "sph_set_transport");
+        }
+    }
 
     if (sph_forces(ctx, SPH_STATE_N) != SPH_OK) die(ctx, "sph_forces");       /* :456 */
     if (sph_zero_boundary_forces(ctx, SPH_STATE_N) != SPH_OK) die(ctx, "sph_zero_boundary_forces"); /* :457-458 */
 
-    write_settings(st.outfile + "_Settings.txt", st.nframes, st.npframe, cs.dt0, cs.pstep, simmass, prm.rho0, prm.H,
-                   -prm.g, prm.bound_parts, simpts);
+    if (root)
+        write_settings(st.outfile + "_Settings.txt", st.nframes, st.npframe, cs.dt0, cs.pstep, simmass, prm.rho0, prm.H,
+                       -prm.g, bound_parts, simpts);
 
-    std::ofstream f1((st.outfile + ".plt").c_str(), std::ios::out);
-    if (f1.is_open()) {
-        f1 << std::fixed << std::setprecision(3);
-        std::cout << "Starting simulation..." << std::endl;
-        f1 << (prm.dim == 3 ? "VARIABLES = x, y, z, V, F, rho, P" : "VARIABLES = x, y, V, F, rho, P") << std::endl;
-        if (sph_download(ctx, SPH_STATE_N, &h) != SPH_OK) die(ctx, "sph_download");
-        write_frame(hs, f1, 0.f, prm.bound_parts, st.program, nthreads);
+    /* One frame's rows into `dst` (rank 0; all particles, original order): a download on one
+     * GPU; otherwise every rank downloads what it owns now and rank 0 places the rows by
+     * their global indices. */
+    auto fetch_frame = [&](int which, HostState* dst) {
+        if (!multi) {
+            sph_fields hf = dst->fields();
+            if (sph_download(ctx, which, &hf) != SPH_OK) die(ctx, "sph_download");
+            return;
+        }
+        uint64_t n_now = 0;
+        if (sph_local_count(ctx, &n_now, nullptr, nullptr) != SPH_OK) die(ctx, "sph_local_count");
+        if (n_now != local.n) {
+            local.resize(prm.dim, (size_t)n_now);
+            gids.resize((size_t)n_now);
+        }
+        sph_fields hl = local.fields();
+        if (sph_download(ctx, which, &hl) != SPH_OK) die(ctx, "sph_download");
+        if (sph_download_global_ids(ctx, gids.data()) != SPH_OK) die(ctx, "sph_download_global_ids");
+        std::vector<char> mine;
+        pack_rows(local, gids, mine);
+        std::vector<std::vector<char> > all;
+        if (!wire.gather(mine.data(), mine.size(), &all)) { std::cerr << wire.error << std::endl; exit(-1); }
+        if (root) {
+            unpack_rows(mine.data(), prm.dim, *dst);
+            for (int k = 1; k < nranks; ++k) unpack_rows(all[(size_t)k].data(), prm.dim, *dst);
+        }
+    };
+
+    std::ofstream f1;
+    if (root) f1.open((st.outfile + ".plt").c_str(), std::ios::out);
+    bool opened = !root || f1.is_open();
+    if (multi) { /* everybody learns whether rank 0 has its file */
+        double v[1] = {opened ? 0.0 : 1.0};
+        if (!wire.allreduce(v, 1, 0)) { std::cerr << wire.error << std::endl; exit(-1); }
+        opened = v[0] == 0.0;
+    }
+    if (opened) {
+        if (root) {
+            f1 << std::fixed << std::setprecision(3);
+            std::cout << "Starting simulation..." << std::endl;
+            f1 << (prm.dim == 3 ? "VARIABLES = x, y, z, V, F, rho, P" : "VARIABLES = x, y, V, F, rho, P") << std::endl;
+        }
+        std::atomic<bool> broken(false); /* set by the writer after the reference's NaN report */
+        fetch_frame(SPH_STATE_N, &hs);
+        if (root && !write_frame(hs, f1, 0.f, bound_parts, st.program, nthreads)) broken = true;
 
         sph_scalars sc;
         if (sph_get_scalars(ctx, &sc) != SPH_OK) die(ctx, "sph_get_scalars");
         HostState* fill = &hs;      /* the set the next download goes to */
         HostState* busy = &hs_alt;  /* the set the writer thread is reading, if one is running */
         std::thread writer;
+        /* The reference stops inside write_frame_data at the first NaN row (WCXSPH3D.cpp:422-431).
+         * Here the file is written by a second thread while the next frame is computed: that thread
+         * only raises a flag; the main thread sees it once the writer has been joined, tells the
+         * other ranks, releases the context and exits -1. */
+        auto stop_if_broken = [&]() {
+            int stop = broken ? 1 : 0;
+            if (multi) {
+                double v[1] = {(double)stop};
+                if (!wire.allreduce(v, 1, 0)) { std::cerr << wire.error << std::endl; exit(-1); }
+                stop = v[0] != 0.0;
+            }
+            if (stop) {
+                sph_destroy(ctx);
+                exit(-1);
+            }
+        };
+        stop_if_broken();
         for (int frame = 1; frame <= st.nframes; ++frame) {
-            std::cout << "Frame Number: " << frame << "\tError: " << log10(sqrt(sc.errsum / (1.0 * prm.npts))) - sc.logbase
-                      << std::endl;
+            if (root)
+                std::cout << "Frame Number: " << frame << "\tError: " << log10(sqrt(sc.errsum / (1.0 * npts_all))) - sc.logbase
+                          << std::endl;
             if (sph_step(ctx, st.npframe, &sc) != SPH_OK) die(ctx, "sph_step");
             if (st.reinit && sph_density_reinit(ctx) != SPH_OK) die(ctx, "sph_density_reinit");
             if (frame % st.frame_stride != 0 && frame != st.nframes) continue;
-            sph_fields hf = fill->fields();
-            if (sph_download(ctx, SPH_STATE_NP1, &hf) != SPH_OK) die(ctx, "sph_download");
+            fetch_frame(SPH_STATE_NP1, fill);
             if (writer.joinable()) writer.join(); /* frames go to the file in order */
-            const float tframe = sc.t;
-            HostState* job = fill;
-            writer = std::thread([&f1, job, tframe, &prm, &st, nthreads]() {
-                write_frame(*job, f1, tframe, prm.bound_parts, st.program, nthreads);
-            });
+            stop_if_broken();
+            if (root) {
+                const float tframe = sc.t;
+                HostState* job = fill;
+                writer = std::thread([&f1, &broken, job, tframe, bound_parts, &st, nthreads]() {
+                    if (!write_frame(*job, f1, tframe, bound_parts, st.program, nthreads)) broken = true;
+                });
+            }
             std::swap(fill, busy);
         }
         if (writer.joinable()) writer.join();
-        f1.close();
+        stop_if_broken();
+        if (root) f1.close();
     } else {
-        std::cerr << "Error opening frame output file." << std::endl;
+        if (root) std::cerr << "Error opening frame output file." << std::endl;
         exit(-1);
     }
     sph_destroy(ctx);
 
-    std::cout << "Simulation complete. Output is available in /Output!" << std::endl;
-    auto t2 = std::chrono::high_resolution_clock::now();
-    auto duration = std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count();
-    std::cout << "Time taken:\t" << duration / 1e06 << " seconds" << std::endl;
+    if (root) {
+        std::cout << "Simulation complete. Output is available in /Output!" << std::endl;
+        auto t2 = std::chrono::high_resolution_clock::now();
+        auto duration = std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count();
+        std::cout << "Time taken:\t" << duration / 1e06 << " seconds" << std::endl;
+    }
     return 0;
 }

@@ -144,3 +144,47 @@ def test_droplet_settings(tmp_path):
     want = oracle_rows(orc, O.STATE_NP1)
     assert got.shape == want.shape
     assert np.all(np.abs(got - want) <= 0.5e-3 + 1e-9 * np.maximum(1.0, np.abs(want)))
+
+
+def test_two_ranks_write_the_same_plt_as_one(tmp_path):
+    # the C++ driver with one process per slab (both on this one GPU, halo bytes staged through
+    # the driver's own sockets): rank 0 gathers the rows and writes the file the single-GPU run
+    # writes, byte for byte (three decimals per value; the fields agree to ~1e-13)
+    import socket
+    spec = util.small_cases()["wcxsph3d_block"]
+    fmt = lambda a: " ".join(repr(float(v)) for v in a)
+
+    def settings(name, extra):
+        path = tmp_path / (name + ".txt")
+        path.write_text("\n".join([
+            "default_params? no", "outfile %s" % (tmp_path / name), "program WCXSPH3D", "nframes 3", "npframe 6",
+            "dt 0.0002", "psize %r" % spec["pstep"], "rho_ref 1000", "viscosity 0.025", "gravity 9.81", "simtype Box",
+            "npart " + " ".join(str(v) for v in spec["npart"]), "box " + fmt(spec["box"]), "start " + fmt(spec["start"]),
+            "reinit 1", "device 0"] + extra + [""]))
+        return str(path)
+
+    one = subprocess.run([SPH_RUN, settings("One", [])], capture_output=True, text=True, timeout=240)
+    assert one.returncode == 0, one.stdout + one.stderr
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cfg = settings("Two", ["transport host", "migrate 1"])
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", SPH_WIRE_PORT=str(port))
+        procs.append(subprocess.Popen([SPH_RUN, cfg], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        o, _ = p.communicate(timeout=240)
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n-----\n".join(outs)
+    assert "Simulation complete." in outs[0] and "Frame Number: 3\tError:" in outs[0]
+    assert "Frame Number" not in outs[1]  # rank 0 speaks for the run
+    a = (tmp_path / "One.plt").read_bytes()
+    b = (tmp_path / "Two.plt").read_bytes()
+    assert len(a) > 100_000 and a == b
+    assert (tmp_path / "One_Settings.txt").read_bytes() == (tmp_path / "Two_Settings.txt").read_bytes()
+    # the convergence line of every frame agrees too (printed at default precision)
+    pick = lambda text: [l for l in text.splitlines() if l.startswith("Frame Number")]
+    assert pick(one.stdout) == pick(outs[0])
