@@ -188,3 +188,24 @@ def test_two_ranks_write_the_same_plt_as_one(tmp_path):
     # the convergence line of every frame agrees too (printed at default precision)
     pick = lambda text: [l for l in text.splitlines() if l.startswith("Frame Number")]
     assert pick(one.stdout) == pick(outs[0])
+
+
+def test_settings_summary_against_the_file_the_reference_ships(tmp_path):
+    # tests/golden/reference_Test_Settings.txt is the one output file the reference repository
+    # holds (Test_Settings.txt, written by an older revision of WCSPH.cpp).  The lines its current
+    # source still determines must come out the same: steps per frame, time step, spacing, mass,
+    # density, support radius, number of simulation points, integrator.  Stale in the shipped file
+    # (see WCSPH.cpp:312-334, 373): 716 boundary points (the source now makes 660) and the sign
+    # of the gravity line; the frame count is overridden here to keep the run short.
+    golden = open(os.path.join(ROOT, "tests", "golden", "reference_Test_Settings.txt")).read().splitlines()
+    cfg = tmp_path / "in.txt"
+    cfg.write_text("default_params? yes\nprogram WCSPH\noutfile %s\nnframes 1\n" % (tmp_path / "Ref"))
+    r = subprocess.run([SPH_RUN, str(cfg)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    mine = (tmp_path / "Ref_Settings.txt").read_text().splitlines()
+    assert len(mine) == len(golden) == 12
+    same = [0, 2, 3, 4, 5, 6, 7, 10, 11]
+    for k in same:
+        assert mine[k] == golden[k], (k, mine[k], golden[k])
+    assert mine[1] == "\tNumber of frames (1)" and golden[1] == "\tNumber of frames (2000)"
+    assert mine[8] == "\tGravitational strength (9.81)" and mine[9] == "\tNumber of boundary points (660)"

@@ -255,6 +255,35 @@ def test_moving_walls_keep_wall_wall_pairs():
     sim.close()
 
 
+def test_a_stray_particle_far_away_keeps_the_sets_exact():
+    # one fluid particle flung far out blows the bounding box up; the cell table cannot grow with
+    # it, so the cells are stretched to many times the list radius.  The single-precision test of
+    # the list build widens its margin with the cell edge: the sets must stay those of the
+    # brute-force search, and a step must still agree with the oracle.
+    spec = CASES["wcxsph3d_block"]
+    orc, sim = start(spec)
+    st = orc.get_state(O.STATE_N)
+    x = st["x"].copy()
+    x[-1] = (3.0e7, 0.6, 0.5)
+    for w, gw in ((O.STATE_N, capi.STATE_N), (O.STATE_NP1, capi.STATE_NP1)):
+        orc.set_state(w, x=x)
+        sim.upload(gw, {"x": np.ascontiguousarray(x.T)})
+    go, gc = sim.neighbours(capi.STATE_NP1)
+    oo, occ = orc.neighbours(O.STATE_NP1, O.SEARCH_BRUTE)
+    assert np.array_equal(go, oo) and np.array_equal(gc, occ)
+    orc.forces(O.STATE_N)
+    orc.zero_boundary_f(O.STATE_N)
+    sim.forces(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    orc.step(2)
+    sim.step(2)
+    assert_state_close(sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1), "stray particle")
+    go, gc = sim.neighbours(capi.STATE_NP1)
+    oo, occ = orc.neighbours(O.STATE_NP1, O.SEARCH_BRUTE)
+    assert np.array_equal(go, oo) and np.array_equal(gc, occ)
+    sim.close()
+
+
 # ---- API behaviour -------------------------------------------------------------------------------
 
 def test_upload_download_round_trip_and_errors():
