@@ -229,6 +229,10 @@ int sph_set_slab_interval(sph_ctx* ctx, double slab_lo, double slab_hi);
  * `unique_id` is the 128-byte ncclUniqueId, identical on all ranks (rank 0 obtains it with
  * sph_rccl_unique_id and the launcher broadcasts it). */
 int sph_rccl_unique_id(void* unique_id_128);
+/* Diagnostic: runs the RCCL transport's own calls on one GPU -- a one-rank communicator, the
+ * grouped send/receive with itself as both neighbours, the grouped max+sum all-reduce -- and
+ * checks what comes back.  `msg` receives "ok" or what failed. */
+int sph_rccl_selftest(int32_t device, char* msg, int32_t msg_len);
 int sph_use_rccl(sph_ctx* ctx, const void* unique_id_128);
 
 /* ---- the reference's case set-up, host side ----------------------------------------- */

@@ -26,7 +26,7 @@ SYMBOLS = (
     "sph_case_default", "sph_case_params", "sph_case_init",
     "sph_set_transport", "sph_upload_global_ids", "sph_rccl_unique_id", "sph_use_rccl",
     "sph_case_init_range", "sph_case_histogram_x", "sph_local_count", "sph_download_global_ids",
-    "sph_set_slab_interval", "sph_halo_counts",
+    "sph_set_slab_interval", "sph_halo_counts", "sph_rccl_selftest",
 )
 
 
@@ -127,6 +127,7 @@ def lib():
     L.sph_set_slab_interval.argtypes = [vp, C.c_double, C.c_double]
     L.sph_halo_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sph_rccl_unique_id.argtypes = [vp]
+    L.sph_rccl_selftest.argtypes = [C.c_int32, C.c_char_p, C.c_int32]
     L.sph_use_rccl.argtypes = [vp, vp]
     L.sph_case_init_range.argtypes = [C.POINTER(Case), C.c_double, C.c_double, C.POINTER(Fields), vp,
                                       C.POINTER(C.c_uint64)]
@@ -144,6 +145,13 @@ def rccl_unique_id():
     if lib().sph_rccl_unique_id(buf) != OK:
         raise SphError("sph_rccl_unique_id failed (is librccl.so.1 on the loader path?)")
     return bytes(buf.raw)
+
+
+def rccl_selftest(device=-1):
+    """Runs the library's RCCL calls on one GPU (a one-rank communicator); returns its message."""
+    buf = C.create_string_buffer(256)
+    rc = lib().sph_rccl_selftest(device, buf, 256)
+    return rc, buf.value.decode()
 
 
 def default_case(program):

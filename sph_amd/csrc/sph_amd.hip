@@ -1953,6 +1953,7 @@ struct RcclState {
     void* lib = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    int peerL = -1, peerR = 1; /* ranks of the slab neighbours */
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -1974,10 +1975,10 @@ static int rccl_sendrecv(void* user, const void* sL, uint64_t nsL, void* rL, uin
     hipStream_t st = (hipStream_t)stream;
     if (!(nsL || nrL || nsR || nrR)) return 0;
     bool ok = r->GroupStart() == ncclSuccess;
-    if (nsL) ok = ok && r->Send(sL, nsL, ncclUint8, r->rank - 1, r->comm, st) == ncclSuccess;
-    if (nrL) ok = ok && r->Recv(rL, nrL, ncclUint8, r->rank - 1, r->comm, st) == ncclSuccess;
-    if (nsR) ok = ok && r->Send(sR, nsR, ncclUint8, r->rank + 1, r->comm, st) == ncclSuccess;
-    if (nrR) ok = ok && r->Recv(rR, nrR, ncclUint8, r->rank + 1, r->comm, st) == ncclSuccess;
+    if (nsL) ok = ok && r->Send(sL, nsL, ncclUint8, r->peerL, r->comm, st) == ncclSuccess;
+    if (nrL) ok = ok && r->Recv(rL, nrL, ncclUint8, r->peerL, r->comm, st) == ncclSuccess;
+    if (nsR) ok = ok && r->Send(sR, nsR, ncclUint8, r->peerR, r->comm, st) == ncclSuccess;
+    if (nrR) ok = ok && r->Recv(rR, nrR, ncclUint8, r->peerR, r->comm, st) == ncclSuccess;
     ok = (r->GroupEnd() == ncclSuccess) && ok;
     return ok ? 0 : 1;
 }
@@ -2005,6 +2006,89 @@ static void rccl_release(void* p) {
     delete r; /* the library handle stays open: other users in the process may share it */
 }
 
+/* Opens the library and looks the calls up; returns nullptr or what is missing. */
+static const char* rccl_load(RcclState** out) {
+    RcclState* r = new RcclState();
+    r->lib = rccl_open();
+    if (!r->lib) {
+        delete r;
+        return "librccl.so.1 could not be opened";
+    }
+#define SYM(field, name)                                                  \
+    r->field = (decltype(r->field))dlsym(r->lib, name);                   \
+    if (!r->field) {                                                      \
+        delete r;                                                         \
+        return "RCCL lacks " name;                                        \
+    }
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(Send, "ncclSend")
+    SYM(Recv, "ncclRecv")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+#undef SYM
+    *out = r;
+    return nullptr;
+}
+
+int sph_rccl_selftest(int32_t device, char* msg, int32_t msg_len) {
+    auto say = [&](const char* m) {
+        if (msg && msg_len > 0) snprintf(msg, (size_t)msg_len, "%s", m);
+    };
+    say("");
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) { say("hipSetDevice failed"); return SPH_EDEVICE; }
+    RcclState* r = nullptr;
+    if (const char* why = rccl_load(&r)) { say(why); return SPH_ECOMM; }
+    ncclUniqueId id;
+    auto get = (ncclResult_t(*)(ncclUniqueId*))dlsym(r->lib, "ncclGetUniqueId");
+    if (!get || get(&id) != ncclSuccess) { say("ncclGetUniqueId failed"); delete r; return SPH_ECOMM; }
+    if (r->CommInitRank(&r->comm, 1, id, 0) != ncclSuccess) { say("ncclCommInitRank (one rank) failed"); delete r; return SPH_ECOMM; }
+    r->rank = 0;
+    r->nranks = 1;
+    r->peerL = r->peerR = 0; /* both neighbours are this rank itself */
+    int rc = SPH_OK;
+    hipStream_t st = nullptr;
+    char* buf = nullptr;
+    const size_t n = 1 << 16; /* bytes per message */
+    std::vector<char> h(4 * n), back(4 * n);
+    double hv[8] = {1.5, -2.0, 3.25, 0.0, 7.0, 10.0, 20.5, -4.0}, hb[8];
+    do {
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&buf, 4 * n + 64) != hipSuccess) {
+            say("stream or buffer could not be made");
+            rc = SPH_EDEVICE;
+            break;
+        }
+        for (size_t k = 0; k < 2 * n; ++k) h[k] = (char)(k * 7 + (k >> 9));
+        /* [0,n) goes left, [n,2n) goes right; what comes from the left lands in [2n,3n), from the right in [3n,4n) */
+        if (hipMemcpyAsync(buf, h.data(), 2 * n, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemsetAsync(buf + 2 * n, 0, 2 * n, st) != hipSuccess) { say("copy failed"); rc = SPH_EDEVICE; break; }
+        if (rccl_sendrecv(r, buf, n, buf + 2 * n, n, buf + n, n, buf + 3 * n, n, (void*)st) != 0) { say("grouped send/recv failed"); rc = SPH_ECOMM; break; }
+        double* dv = (double*)(buf + 4 * n);
+        if (hipMemcpyAsync(dv, hv, sizeof hv, hipMemcpyHostToDevice, st) != hipSuccess) { say("copy failed"); rc = SPH_EDEVICE; break; }
+        if (rccl_allreduce_max_sum(r, dv, RED_NMAX, dv + RED_NMAX, RED_NSUM, (void*)st) != 0) { say("grouped all-reduce failed"); rc = SPH_ECOMM; break; }
+        if (rccl_allreduce(r, dv, 2, 0, (void*)st) != 0 || rccl_allreduce(r, dv + 2, 2, 1, (void*)st) != 0) { say("all-reduce failed"); rc = SPH_ECOMM; break; }
+        if (hipMemcpyAsync(back.data(), buf, 4 * n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(hb, dv, sizeof hb, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            say("copy back failed");
+            rc = SPH_EDEVICE;
+            break;
+        }
+        /* with itself as both neighbours the first message sent is the first received */
+        if (memcmp(back.data() + 2 * n, h.data(), n) != 0 || memcmp(back.data() + 3 * n, h.data() + n, n) != 0) {
+            say("send/recv delivered other bytes");
+            rc = SPH_ECOMM;
+            break;
+        }
+        if (memcmp(hb, hv, sizeof hv) != 0) { say("a one-rank all-reduce changed the values"); rc = SPH_ECOMM; break; }
+        say("ok");
+    } while (0);
+    if (buf) (void)hipFree(buf);
+    if (st) (void)hipStreamDestroy(st);
+    rccl_release(r);
+    return rc;
+}
+
 int sph_rccl_unique_id(void* unique_id_128) {
     if (!unique_id_128) return SPH_EINVAL;
     void* lib = rccl_open();
@@ -2022,28 +2106,12 @@ int sph_use_rccl(sph_ctx* c, const void* unique_id_128) {
     if (!c->dist) return fail(c, SPH_ESTATE, "a transport is only used when nranks > 1");
     if (c->rccl) return fail(c, SPH_ESTATE, "the RCCL transport is already installed");
     HIPCHK(hipSetDevice(c->device));
-    RcclState* r = new RcclState();
-    r->lib = rccl_open();
-    if (!r->lib) {
-        delete r;
-        return fail(c, SPH_ECOMM, "librccl.so.1 could not be opened");
-    }
-#define SYM(field, name)                                                  \
-    r->field = (decltype(r->field))dlsym(r->lib, name);                   \
-    if (!r->field) {                                                      \
-        delete r;                                                         \
-        return fail(c, SPH_ECOMM, "RCCL lacks " name);                    \
-    }
-    SYM(CommInitRank, "ncclCommInitRank")
-    SYM(CommDestroy, "ncclCommDestroy")
-    SYM(Send, "ncclSend")
-    SYM(Recv, "ncclRecv")
-    SYM(AllReduce, "ncclAllReduce")
-    SYM(GroupStart, "ncclGroupStart")
-    SYM(GroupEnd, "ncclGroupEnd")
-#undef SYM
+    RcclState* r = nullptr;
+    if (const char* why = rccl_load(&r)) return fail(c, SPH_ECOMM, why);
     r->rank = c->rank;
     r->nranks = c->nranks;
+    r->peerL = c->rank - 1;
+    r->peerR = c->rank + 1;
     ncclUniqueId id;
     memcpy(&id, unique_id_128, sizeof id);
     const ncclResult_t ir = r->CommInitRank(&r->comm, c->nranks, id, c->rank);

@@ -270,3 +270,12 @@ def test_density_reinit_across_slabs_with_particles_changing_owner(tmp_path):
     o = orc.get_state(O.STATE_N)
     for k in ("x", "v", "f"):
         assert util.rel_err(res["step_" + k].T, o[k]) <= TOL, k
+
+
+def test_rccl_calls_on_a_one_rank_communicator():
+    # RCCL refuses two ranks on one GPU, so the multi-rank tests above move their bytes through
+    # gloo; this runs the library's own RCCL transport functions (grouped send/recv, grouped
+    # max+sum all-reduce) on a communicator of one rank with itself as both neighbours
+    from sph_amd import capi
+    rc, msg = capi.rccl_selftest(0)
+    assert rc == 0 and msg == "ok", msg
