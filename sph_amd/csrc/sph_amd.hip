@@ -97,6 +97,7 @@ struct sph_ctx {
     bool lists_for_step = false; /* built by the stepping path (wall-wall pairs may be left out) */
     double skin_frac = 0.05, r_list2 = 0, disp_limit = 0;
     uint32_t brick_log2 = 2;
+    uint32_t sub_bits = 0; /* sort-key bits per axis below the cell (SPH_SUB_BITS) */
     double disp_host = 0;
     /* The skin follows the motion unless the caller fixed it: step_travel is a running upper
      * estimate of how far the fastest particle gets in one step (the same number on every rank
@@ -115,6 +116,7 @@ struct sph_ctx {
     double* scratch = nullptr; /* device address of this device's scratch array */
     bool no_alloc = false;     /* the call under way may not allocate or free device memory */
     bool trace = false;        /* SPH_TRACE=1: a line per list rebuild on stderr */
+    uint64_t draws = 0;
     double* bbox_part = nullptr;
     double* bbox_host = nullptr; /* pinned */
     uint32_t* need_host = nullptr; /* pinned, 8 words */
@@ -265,7 +267,7 @@ int exclusive_scan(sph_ctx* c, const uint32_t* in, uint32_t* out, uint32_t n) {
 /* Sorts m (key, position) pairs; on return `keys` holds the sorted keys and `perm` the old
  * position of each sorted entry (the four pointers are swapped as the passes ping-pong). */
 int radix_sort(sph_ctx* c, uint32_t*& keys, uint32_t*& keys_alt, uint32_t*& perm, uint32_t*& perm_alt, uint32_t m,
-               uint32_t ncells) {
+               uint64_t ncells) {
     if (m == 0) return SPH_OK;
     const uint32_t nb = (m + RS_TILE - 1) / RS_TILE;
     const size_t hsz = (size_t)256 * nb;
@@ -304,7 +306,10 @@ void launch_hash(sph_ctx* c, const Rec* r, uint32_t m, const uint32_t* drop, uin
 inline DPos* dpos_of(sph_ctx* c) { return (DPos*)((char*)c->rec_alt + (size_t)c->cap * 16); }
 inline uint32_t* cellc_of(sph_ctx* c) { return (uint32_t*)((char*)c->rec_alt + (size_t)c->cap * 32); }
 
-int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
+int ensure_step_lists(sph_ctx* c, bool* ok);
+
+/* with_step_lists: the build writes the step lists too (radius r_in2), on the same positions */
+int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below, bool with_step_lists) {
     const uint32_t* hb = c->n_halo ? c->hbeg : nullptr;
     const uint32_t* he = c->n_halo ? c->hend : nullptr;
     /* positions and wall ids of the owned and the neighbours' particles, packed for the build
@@ -315,12 +320,18 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below) {
     const Pos* pos = (const Pos*)c->rec_alt;
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
+        if (with_step_lists) { /* as many rows again, of the same length */
+            bool ok = true;
+            CHK(ensure_step_lists(c, &ok));
+        }
+        uint32_t* const tin = with_step_lists ? c->nbr_in : nullptr;
+        uint32_t* const tcnt = with_step_lists ? c->cnt_in : nullptr;
         if (c->dim == 3)
             hipLaunchKernelGGL(k_build_list<3>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, pos, c->n, c->grid, c->cbeg,
-                               c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below, hb, he);
+                               c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below, hb, he, c->r_in2, tin, tcnt);
         else
             hipLaunchKernelGGL(k_build_list<2>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, pos, c->n, c->grid, c->cbeg,
-                               c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below, hb, he);
+                               c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below, hb, he, c->r_in2, tin, tcnt);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -506,7 +517,8 @@ int exchange_halo_at_rebuild(sph_ctx* c, int src, const double thr[2]) {
     /* sort the halo region by cell */
     launch_hash(c, r + n, m, nullptr, c->keys + n);
     uint32_t *k = c->keys + n, *ka = c->keys_alt + n, *p = c->perm + n, *pa = c->perm_alt + n;
-    CHK(radix_sort(c, k, ka, p, pa, m, c->grid.ncells));
+    const uint32_t sub_all = c->grid.sub * (uint32_t)c->dim;
+    CHK(radix_sort(c, k, ka, p, pa, m, (uint64_t)c->grid.ncells << sub_all));
     if (k != c->keys + n) HIPCHK(hipMemcpyAsync(c->keys + n, k, (size_t)m * 4, hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(k_reorder_halo, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, p, m, r + n, c->rec_alt + n, c->gid + n,
                        c->gid_alt + n);
@@ -515,7 +527,7 @@ int exchange_halo_at_rebuild(sph_ctx* c, int src, const double thr[2]) {
     hipLaunchKernelGGL(k_halo_pos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, p, m, n, c->halo_pos);
     HIPCHK(hipMemsetAsync(c->hbeg, 0xFF, sizeof(uint32_t) * c->grid.ncells, c->stream));
     HIPCHK(hipMemsetAsync(c->hend, 0, sizeof(uint32_t) * c->grid.ncells, c->stream));
-    hipLaunchKernelGGL(k_cell_mark, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, c->keys + n, m, n, c->hbeg, c->hend);
+    hipLaunchKernelGGL(k_cell_mark, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, c->keys + n, m, n, c->hbeg, c->hend, sub_all);
     HIPCHK(hipGetLastError());
     return SPH_OK;
 }
@@ -750,13 +762,16 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     }
     if (ncells == 0) return fail(c, SPH_ESTATE, "cell grid exceeds its table");
     g.ncells = (uint32_t)ncells;
+    g.sub = c->sub_bits;
+    while (g.sub > 0 && (((uint64_t)ncells + 1) << (g.sub * (uint32_t)dim)) > (1ull << 32)) --g.sub; /* keys are 32 bits */
     c->grid = g;
     /* the draw refers to a particle's cell through a packed word */
     if (g.n[0] > CELLC_MAX_X || g.n[1] > CELLC_MAX_YZ || g.n[2] > CELLC_MAX_YZ) c->two_level = false;
 
     /* sort the owned particles by cell */
     launch_hash(c, c->rec[src], m_sort, drop, c->keys);
-    CHK(radix_sort(c, c->keys, c->keys_alt, c->perm, c->perm_alt, m_sort, g.ncells + (drop ? 1u : 0u)));
+    const uint32_t sub_all = g.sub * (uint32_t)dim;
+    CHK(radix_sort(c, c->keys, c->keys_alt, c->perm, c->perm_alt, m_sort, ((uint64_t)g.ncells + (drop ? 1u : 0u)) << sub_all));
     /* the leavers sorted behind every cell; from here on this rank owns n particles */
     c->n = n;
     c->dp.n = n;
@@ -835,7 +850,7 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     /* cell table of the owned particles */
     HIPCHK(hipMemsetAsync(c->cbeg, 0xFF, sizeof(uint32_t) * g.ncells, c->stream));
     HIPCHK(hipMemsetAsync(c->cend, 0, sizeof(uint32_t) * g.ncells, c->stream));
-    hipLaunchKernelGGL(k_cell_mark, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->keys, n, 0u, c->cbeg, c->cend);
+    hipLaunchKernelGGL(k_cell_mark, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->keys, n, 0u, c->cbeg, c->cend, sub_all);
     HIPCHK(hipGetLastError());
 
     if (c->dist) {
@@ -853,7 +868,7 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
         };
         const uint32_t colsL = c->has_side[0] ? std::min(cols, (cellx(thr_send[0]) >> g.ts[0]) + 1u) : 0u;
         const uint32_t colR0 = c->has_side[1] ? (cellx(thr_send[1]) >> g.ts[0]) : cols;
-        hipLaunchKernelGGL(k_lower_bounds, dim3(1), dim3(1), 0, c->stream, c->keys, n, colsL * col, colR0 * col, c->need + 2);
+        hipLaunchKernelGGL(k_lower_bounds, dim3(1), dim3(1), 0, c->stream, c->keys, n, (colsL * col) << sub_all, (colR0 * col) << sub_all, c->need + 2);
         HIPCHK(hipMemcpyAsync(c->need_host + 6, c->need + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         c->iL_end = c->has_side[0] ? c->need_host[6] : 0;
@@ -874,7 +889,8 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
         c->outer_budget = 0.5 * (r_list - r_in) * 0.999;
     }
     const uint32_t wall_below = (for_step && c->dp.bound_parts > 0 && walls_move == 0.0) ? c->dp.bound_parts : 0u;
-    CHK(build_lists(c, c->rec[src], wall_below));
+    CHK(build_lists(c, c->rec[src], wall_below, c->two_level));
+    c->step_lists_valid = c->two_level; /* drawn on these very positions */
     c->lists_for_step = for_step;
     c->use_nbr = c->nbr;
     c->use_cnt = c->cnt;
@@ -974,6 +990,19 @@ int draw_step_lists(sph_ctx* c, const Rec* r) {
                            c->nbr_in, c->cnt_in, c->S);
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
+    if (c->trace && (c->draws++ % 16) == 0) { /* how the drawn rows fill the pair kernel's waves */
+        unsigned long long* d = (unsigned long long*)c->tmp;
+        unsigned long long h[6];
+        HIPCHK(hipMemsetAsync(d, 0, sizeof h, c->stream));
+        hipLaunchKernelGGL(k_rounds_stats, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, c->cnt_in, c->n, d);
+        hipLaunchKernelGGL(k_rounds_stats, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, c->cnt, c->n, d + 3);
+        HIPCHK(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const double waves = (c->n + 15) / 16;
+        fprintf(stderr, "[sph] draw: step lists %.2f entries/particle, %.2f rounds/wave run for %.2f needed per particle; "
+                        "candidates %.2f entries/particle, %.2f rounds/wave\n",
+                (double)h[2] / c->n, h[0] / waves, (double)h[1] / c->n, (double)h[5] / c->n, h[3] / waves);
+    }
     return SPH_OK;
 }
 
@@ -1305,6 +1334,7 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     if (const char* e = getenv("SPH_SKIN_K2")) c->skin_k2 = atof(e);
     c->brick_log2 = c->dim == 3 ? 2u : 3u;
     if (const char* e = getenv("SPH_BRICK_LOG2")) c->brick_log2 = (uint32_t)std::min(5, std::max(0, atoi(e)));
+    if (const char* e = getenv("SPH_SUB_BITS")) c->sub_bits = (uint32_t)std::min(3, std::max(0, atoi(e)));
 
     DevParams& d = c->dp;
     memset(&d, 0, sizeof d);

@@ -142,14 +142,31 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_hash(const Rec* __restrict__ rec,
                                                     uint32_t* __restrict__ keys) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= n) return;
+    const uint32_t sub_all = g.sub * (uint32_t)DIM;
     if (drop && drop[i]) { /* handed to a neighbouring slab: sorts behind every cell */
-        keys[i] = g.ncells;
+        keys[i] = g.ncells << sub_all;
         return;
     }
-    const int cx = cell_coord(rec[i].xv[0][0], g.lo[0], g.inv[0], g.n[0]);
-    const int cy = cell_coord(rec[i].xv[1][0], g.lo[1], g.inv[1], g.n[1]);
-    const int cz = DIM == 3 ? cell_coord(rec[i].xv[2][0], g.lo[2], g.inv[2], g.n[2]) : 0;
-    keys[i] = cell_key<DIM>(g, cx, cy, cz);
+    const double x = rec[i].xv[0][0], y = rec[i].xv[1][0], z = DIM == 3 ? rec[i].xv[2][0] : 0.0;
+    const int cx = cell_coord(x, g.lo[0], g.inv[0], g.n[0]);
+    const int cy = cell_coord(y, g.lo[1], g.inv[1], g.n[1]);
+    const int cz = DIM == 3 ? cell_coord(z, g.lo[2], g.inv[2], g.n[2]) : 0;
+    /* Below the cell, the particle's place inside it (2^sub parts per axis, x slowest): the
+     * order inside a cell is free, and an order that follows space keeps the particles of a
+     * wave, and what they gather, together however often the cells have been re-sorted. */
+    uint32_t low = 0;
+    if (g.sub) {
+        const double parts = (double)(1u << g.sub);
+        auto part = [&](double v, double lo, double inv, int c) {
+            double f = ((v - lo) * inv - (double)c) * parts;
+            f = fmin(fmax(f, 0.0), parts - 1.0); /* NaN -> 0; particles outside the box sit in edge cells */
+            return (uint32_t)f;
+        };
+        low = part(x, g.lo[0], g.inv[0], cx);
+        low = (low << g.sub) | part(y, g.lo[1], g.inv[1], cy);
+        if (DIM == 3) low = (low << g.sub) | part(z, g.lo[2], g.inv[2], cz);
+    }
+    keys[i] = (cell_key<DIM>(g, cx, cy, cz) << sub_all) | low;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -376,12 +393,12 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reorder(ReorderArgs a) {
 
 __global__ __launch_bounds__(SPH_BLOCK) void k_cell_mark(const uint32_t* __restrict__ keys, uint32_t n,
                                                          uint32_t index_base, uint32_t* __restrict__ cbeg,
-                                                         uint32_t* __restrict__ cend) {
+                                                         uint32_t* __restrict__ cend, uint32_t sub_all) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const uint32_t k = keys[i];
-    if (i == 0 || keys[i - 1] != k) cbeg[k] = index_base + i;
-    if (i == n - 1 || keys[i + 1] != k) cend[k] = index_base + i + 1;
+    const uint32_t k = keys[i] >> sub_all; /* the cell; the bits below order the particles inside it */
+    if (i == 0 || (keys[i - 1] >> sub_all) != k) cbeg[k] = index_base + i;
+    if (i == n - 1 || (keys[i + 1] >> sub_all) != k) cend[k] = index_base + i + 1;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -564,7 +581,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
                                                           uint32_t* __restrict__ nbr, uint32_t stride, uint32_t cap,
                                                           uint32_t* __restrict__ cnt, uint32_t* __restrict__ need,
                                                           uint32_t wall_below, const uint32_t* __restrict__ hbeg,
-                                                          const uint32_t* __restrict__ hend) {
+                                                          const uint32_t* __restrict__ hend, double rin2,
+                                                          uint32_t* __restrict__ nbr_in, uint32_t* __restrict__ cnt_in) {
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
     const uint32_t i_raw = xcd_contiguous_block() * (SPH_BLOCK / 4) + (threadIdx.x >> 2);
     const bool active = i_raw < n;
@@ -579,6 +597,11 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
     const int cy = cell_coord(yi, g.lo[1], g.inv[1], g.n[1]);
     const int cz = DIM == 3 ? cell_coord(zi, g.lo[2], g.inv[2], g.n[2]) : 0;
     uint32_t* const row = nbr + (size_t)i * stride;
+    /* nbr_in != nullptr: the step lists (the candidates within the smaller radius rin2, same
+     * order) are written as well, which saves the draw that would follow the rebuild */
+    uint32_t* const row_in = nbr_in ? nbr_in + (size_t)i * stride : nullptr;
+    const float rin2f = (float)(rin2 * (1.0 + list_float_margin(1.0 / g.inv[0], sqrt(rl2))));
+    uint32_t k_in = 0;
     /* A neighbouring cell is skipped when even its nearest point is out of reach.  Distances in
      * cell edges: fx is the particle's place inside its cell, the gap to a cell on the low side
      * is fx, on the high side 1 - fx (never negative, and the bound carries a margin far above
@@ -608,6 +631,16 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
             if (keepa && ata < cap) row[ata] = ja;
             if (keepb && atb < cap) row[atb] = jb;
             k += __popc(bitsa) + __popc(bitsb);
+            if (row_in) {
+                const bool ina = keepa & (d2a <= rin2f), inb = keepb & (d2b <= rin2f);
+                const uint32_t ia = (uint32_t)(__ballot(ina) >> (lane & 60u)) & 0xFu;
+                const uint32_t ib = (uint32_t)(__ballot(inb) >> (lane & 60u)) & 0xFu;
+                const uint32_t pa_ = k_in + __popc(ia & below);
+                const uint32_t pb_ = k_in + __popc(ia) + __popc(ib & below);
+                if (ina && pa_ < cap) row_in[pa_] = ja;
+                if (inb && pb_ < cap) row_in[pb_] = jb;
+                k_in += __popc(ia) + __popc(ib);
+            }
         }
     };
     /* per x-layer of cells: the cell-table entries of its 9 (3) cells are requested together,
@@ -651,7 +684,23 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
     if (active && q == 0) {
         cnt[i] = k < cap ? k : cap;
         if (k > cap) atomicMax(need, k);
+        if (row_in) cnt_in[i] = k_in < cap ? k_in : cap;
     }
+}
+
+/* Diagnostic (SPH_TRACE): how well the rows of one list fill the pair kernel's waves.  A wave
+ * takes 16 consecutive particles and runs max(ceil(count/4)) rounds.  out[0] += rounds summed
+ * over the waves, out[1] += sum of ceil(count/4) over the particles, out[2] += entries. */
+__global__ __launch_bounds__(SPH_BLOCK) void k_rounds_stats(const uint32_t* __restrict__ cnt, uint32_t n,
+                                                            unsigned long long* __restrict__ out) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    const uint32_t c = i < n ? cnt[i] : 0u;
+    uint32_t r = (c + 3u) >> 2, m = r;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 15u) == 0) atomicAdd(out, (unsigned long long)m);
+    atomicAdd(out + 1, (unsigned long long)r);
+    atomicAdd(out + 2, (unsigned long long)c);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -42,6 +42,7 @@ struct GridParams {
     int32_t  nt[3];   /* bricks per axis */
     uint32_t ts[3];   /* log2 of the brick edge in cells */
     uint32_t ncells;
+    uint32_t sub;     /* sort-key bits below the cell: the particle's place inside its cell, per axis */
 };
 
 /* Device-resident run state: the reference's file-scope globals (WCXSPH3D.cpp:70-79) plus

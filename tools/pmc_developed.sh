@@ -1,0 +1,21 @@
+#!/bin/bash
+# Counter passes of the pair kernel over the default bench run (at rest first, developed flow
+# last): one rocprofv3 run per pass, counters only.  usage: tools/pmc_developed.sh <outdir>
+set -u
+out=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p "$out"
+run() {
+  name=$1; ctrs=$2; shift 2
+  timeout -s KILL 280 rocprofv3 --pmc $ctrs --kernel-include-regex "k_pair" --output-format csv -d "$out/$name" -- python bench.py --steps 5 --warmup 2 --no-cpu "$@" > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$out/$name.log"; return 1; }
+  echo "pass $name ok"
+}
+run fetch "FETCH_SIZE" "$@" &&
+run write "WRITE_SIZE" "$@" &&
+run tcc1 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "$@" &&
+run sq1 "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "$@" &&
+run sq2 "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAIT_INST_LDS" "$@" &&
+run ta "TA_BUSY_avr TA_BUSY_max" "$@" &&
+run grbm "GRBM_GUI_ACTIVE GRBM_COUNT" "$@"
+python tools/pmc_phases.py "$out" > "$out/summary.txt" 2>&1
+cat "$out/summary.txt"
