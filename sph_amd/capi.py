@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsph_amd.so")
+# SPH_AMD_LIB: another build of the same library (development experiments)
+LIB_PATH = os.environ.get("SPH_AMD_LIB") or os.path.join(_HERE, "lib", "libsph_amd.so")
 
 OK, EINVAL, EDEVICE, ENOMEM, ESTATE, ECOMM = range(6)
 VARIANT_WCSPH, VARIANT_WCXSPH = 0, 1

@@ -1744,22 +1744,25 @@ int sph_density_reinit(sph_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     if (!c->ri_pend) {
         CHK(dalloc(c, &c->ri_pend, c->cap));
-        CHK(dalloc(c, &c->ri_queue, c->cap));
+        CHK(dalloc(c, &c->ri_queue, (size_t)3 * c->cap)); /* three frontier queues used in turn */
         CHK(dalloc(c, &c->ri_ctl, 1));
     }
     /* complete lists (wall-wall pairs included) on the positions of state n+1; a slab run
      * fetches its neighbours' particles with them */
     CHK(rebuild(c, c->b0));
     const uint32_t n = c->n;
+    const uint32_t qcap = c->cap;
     Rec* r = c->rec[c->b0];
     const uint32_t* ids = wall_ids(c); /* the walk's order: original index, global in a slab run */
     HIPCHK(hipMemsetAsync(c->ri_ctl, 0, sizeof(ReinitCtl), c->stream));
-#define RI(K, ...)                                                                                              \
-    do {                                                                                                        \
-        if (c->dim == 3) hipLaunchKernelGGL(K<3>, __VA_ARGS__, c->dp, r, c->nbr, c->cap_k, c->cnt, ids,          \
-                                            c->ri_pend, c->ri_queue, c->ri_ctl);                                \
-        else hipLaunchKernelGGL(K<2>, __VA_ARGS__, c->dp, r, c->nbr, c->cap_k, c->cnt, ids, c->ri_pend,         \
-                                c->ri_queue, c->ri_ctl);                                                        \
+    uint32_t level = 0; /* the next level to launch */
+#define RI_LEVEL()                                                                                                        \
+    do {                                                                                                                  \
+        if (c->dim == 3) hipLaunchKernelGGL(k_reinit_level<3>, dim3(grid), dim3(REINIT_LEVEL_THREADS), 0, c->stream, c->dp, r, \
+                                            c->nbr, c->cap_k, c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, qcap, level); \
+        else hipLaunchKernelGGL(k_reinit_level<2>, dim3(grid), dim3(REINIT_LEVEL_THREADS), 0, c->stream, c->dp, r, c->nbr,    \
+                                c->cap_k, c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, qcap, level);                     \
+        ++level;                                                                                                          \
     } while (0)
     uint32_t* touches = c->dist ? c->flags : nullptr;
     if (c->dim == 3)
@@ -1768,7 +1771,6 @@ int sph_density_reinit(sph_ctx* c) {
     else
         hipLaunchKernelGGL(k_reinit_count<2>, dim3((n + SPH_BLOCK / 4 - 1) / (SPH_BLOCK / 4)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k, c->cnt,
                            ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches);
-    hipLaunchKernelGGL(k_reinit_start, dim3(1), dim3(1), 0, c->stream, c->ri_ctl);
     HIPCHK(hipGetLastError());
     ReinitCtl* h = (ReinitCtl*)c->need_host; /* pinned, 8 words */
     if (c->dist) {
@@ -1783,15 +1785,15 @@ int sph_density_reinit(sph_ctx* c) {
         const int batch = 16, grid = 256;
         uint32_t done_before = 0;
         for (uint64_t round = 0;; ++round) {
-            for (;;) { /* the local walk, until its queue runs dry */
-                for (int b = 0; b < batch; ++b) RI(k_reinit_level, dim3(grid), dim3(REINIT_LEVEL_THREADS), 0, c->stream);
+            for (;;) { /* the local walk, until its frontier is empty */
+                for (int b = 0; b < batch; ++b) RI_LEVEL();
                 c->reinit_launches += batch;
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(hipStreamSynchronize(c->stream));
-                if (h->begin == h->end) break;
+                if (h->cnt[level % 3u] == 0) break;
             }
-            const uint32_t done_now = h->begin;
+            const uint32_t done_now = h->done;
             /* finished shared particles go to the neighbours */
             uint2* const sb = (uint2*)c->sendbuf;
             uint2* const rb = (uint2*)c->recvbuf;
@@ -1812,18 +1814,18 @@ int sph_density_reinit(sph_ctx* c) {
             if (c->nrecv[1])
                 hipLaunchKernelGGL(k_reinit_unpack, dim3(nblk(c->nrecv[1])), dim3(SPH_BLOCK), 0, c->stream, rb + hc,
                                    c->halo_pos + c->nrecv[0], c->nrecv[1], r, c->ri_pend);
+            /* those set free by the neighbours' news join the frontier of the next level */
             if (c->dim == 3)
                 hipLaunchKernelGGL(k_reinit_rescan<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
-                                   c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches);
+                                   c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches, qcap, level);
             else
                 hipLaunchKernelGGL(k_reinit_rescan<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
-                                   c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches);
-            hipLaunchKernelGGL(k_reinit_resume, dim3(1), dim3(1), 0, c->stream, c->ri_ctl);
+                                   c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches, qcap, level);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             /* all ranks: particles not finished yet, and whether this round moved anything */
-            double v[2] = {(double)(n - done_now), (double)(done_now - done_before) + (double)(h->tail - done_now)};
+            double v[2] = {(double)(n - done_now), (double)(done_now - done_before) + (double)h->cnt[level % 3u]};
             CHK(allreduce_host(c, v, 2, 1));
             c->reinit_rounds = round + 1;
             if (v[0] == 0.0) break;
@@ -1831,29 +1833,34 @@ int sph_density_reinit(sph_ctx* c) {
             done_before = done_now;
         }
     } else if (n <= REINIT_SINGLE_MAX) { /* a small case is walked by one workgroup, level after level */
-        RI(k_reinit_single, dim3(1), dim3(REINIT_SINGLE_THREADS), 0, c->stream);
+        if (c->dim == 3)
+            hipLaunchKernelGGL(k_reinit_single<3>, dim3(1), dim3(REINIT_SINGLE_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
+                               c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl);
+        else
+            hipLaunchKernelGGL(k_reinit_single<2>, dim3(1), dim3(REINIT_SINGLE_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
+                               c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (h->begin != n || h->tail != n)
+        if (h->done != n || h->cnt[0] != n)
             return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
     } else {
-    /* one launch per dependency level; the host looks at the queue every so often */
-    const int batch = 256, grid = 256; /* one wavefront per released particle, 4096 per pass of the grid */
-    for (uint64_t guard = 0;; ++guard) {
-        for (int b = 0; b < batch; ++b) RI(k_reinit_level, dim3(grid), dim3(REINIT_LEVEL_THREADS), 0, c->stream);
-        c->reinit_launches += batch;
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (h->begin == h->end) {
-            if (h->tail != n) return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
-            break;
+        /* one launch per dependency level; the host looks at the queues every so often */
+        const int batch = 256, grid = 256; /* one wavefront per released particle, 4096 per pass of the grid */
+        for (uint64_t guard = 0;; ++guard) {
+            for (int b = 0; b < batch; ++b) RI_LEVEL();
+            c->reinit_launches += batch;
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (h->cnt[level % 3u] == 0) {
+                if (h->done != n) return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
+                break;
+            }
+            if (guard > (uint64_t)n / batch + 4) return fail(c, SPH_ESTATE, "density re-initialisation did not finish");
         }
-        if (guard > (uint64_t)n / batch + 4) return fail(c, SPH_ESTATE, "density re-initialisation did not finish");
     }
-    }
-#undef RI
+#undef RI_LEVEL
     /* p/rho^2 of the records follows the new rho (Forces forms it from p and rho, WCXSPH3D.cpp:180) */
     hipLaunchKernelGGL(k_fix_prr, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, r, c->pp, n);
     HIPCHK(hipGetLastError());

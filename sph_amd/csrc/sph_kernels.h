@@ -1544,13 +1544,14 @@ __global__ void k_apply_global(DevParams P, DevScalars* S, const double* __restr
 /* is processed by one launch, which in turn releases the next frontier.  Same values as the    */
 /* sequential walk, in as many launches as the longest dependency chain.                       */
 
+/* The frontier of a level sits in one of three queues, used in turn: level L reads queue L % 3
+ * (cnt[L % 3] entries), collects the particles it sets free in queue (L+1) % 3, and clears the
+ * count of queue (L+2) % 3 for the level after.  A launch therefore knows where its frontier is
+ * without waiting for a control word to be published by its predecessor. */
 struct ReinitCtl {
-    uint32_t begin, end; /* queue range of the frontier the next launch processes */
-    uint32_t tail;       /* end of the queue */
-    uint32_t ticket;     /* blocks of the running launch that have finished */
+    uint32_t cnt[3];
+    uint32_t done; /* particles of the levels launched so far */
 };
-/* k_reinit_level adds to tail and ticket with one 8-byte atomic (tail is the low word) */
-static_assert(offsetof(ReinitCtl, tail) == 8 && offsetof(ReinitCtl, ticket) == 12, "tail and ticket form one aligned 8-byte word");
 
 /* W2Kernel (WCXSPH3D.cpp:121-128) */
 __device__ __forceinline__ double w2_kernel(const DevParams& P, double r) {
@@ -1700,7 +1701,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_count(DevParams P, const R
     if (!active || q != 0) return;
     pend[i] = lower;
     if (touches) touches[i] = far;
-    if (lower == 0) queue[atomicAdd(&ctl->tail, 1u)] = i;
+    if (lower == 0) queue[atomicAdd(&ctl->cnt[0], 1u)] = i; /* the first frontier: queue 0 */
 }
 
 /* Slab runs, between two local walks: what the neighbours report of their particles that this
@@ -1728,7 +1729,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_rescan(DevParams P, const 
                                                              const uint32_t* __restrict__ nbr, uint32_t stride,
                                                              const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
                                                              uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
-                                                             ReinitCtl* __restrict__ ctl, const uint32_t* __restrict__ touches) {
+                                                             ReinitCtl* __restrict__ ctl, const uint32_t* __restrict__ touches,
+                                                             uint32_t qcap, uint32_t level) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= P.n || !touches[i] || pend[i] == REINIT_DONE) return;
     const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
@@ -1742,18 +1744,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_rescan(DevParams P, const 
     /* the local walk has run dry, so nothing else touches pend[i] now; a waiting particle's
      * count was above zero until this recount */
     pend[i] = lower;
-    if (lower == 0) queue[atomicAdd(&ctl->tail, 1u)] = i;
-}
-/* the particles queued since the last walk are the next frontier */
-__global__ void k_reinit_resume(ReinitCtl* ctl) {
-    ctl->end = ctl->tail;
-    ctl->ticket = 0;
-}
-
-__global__ void k_reinit_start(ReinitCtl* ctl) {
-    ctl->begin = 0;
-    ctl->end = ctl->tail;
-    ctl->ticket = 0;
+    /* the particles set free here join the frontier of the next level to be launched */
+    if (lower == 0) queue[(size_t)(level % 3u) * qcap + atomicAdd(&ctl->cnt[level % 3u], 1u)] = i;
 }
 
 /* One wavefront per released particle: the lanes share out its candidates, partial sums are
@@ -1761,8 +1753,16 @@ __global__ void k_reinit_start(ReinitCtl* ctl) {
  * small system, lane 0 stores rho, and each lane releases the waiting neighbours among its
  * candidates. */
 __device__ __forceinline__ double wave_allsum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    /* inside a row of sixteen lanes by data-parallel-primitive moves (a few cycles each, against
+     * an LDS round trip for a cross-lane read): partners 1 and 2 apart in the quad, then the
+     * mirror image within eight and within sixteen lanes -- after the quad steps every lane of a
+     * quad holds the quad's sum, so the mirror pairs whole quads.  Then across the four rows. */
+    v += quad_perm_d<QP_XOR1>(v);
+    v += quad_perm_d<QP_XOR2>(v);
+    v += quad_perm_d<0x141>(v); /* row_half_mirror */
+    v += quad_perm_d<0x140>(v); /* row_mirror */
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
     return v;
 }
 
@@ -1830,12 +1830,23 @@ __device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__
         return b;
     };
     auto fetch = [&](uint32_t k) { return fetch_j(nbr[(size_t)i * stride + k]); };
+    /* A finished particle releases the neighbours that were waiting for it.  Which ones is
+     * known as soon as the candidates are in, and whoever reads this particle's new rho does so
+     * after the level's end (a kernel boundary, or the workgroup barrier of the one-workgroup
+     * walk): the counters are lowered now, so that the atomics' round trips and the queueing run
+     * beside the sums and the solve instead of after them.  (A neighbouring rank's particle,
+     * at a position >= P.n, is released by its owner.) */
+    auto lower = [&](const Nb& b) {
+        if (b.in && b.idj > me && b.j < P.n && atomicSub(&pend[b.j], 1u) == 1u) release(b.j);
+    };
     /* the first 64 candidates stay in registers for the second pass */
     Nb first = fetch_j(j_first);
     first.in = first.in && lane < c;
+    lower(first);
     if (first.in) add_A(first.e, first.W, first.m, first.rho);
     for (uint32_t k = lane + 64; k < c; k += 64) {
         const Nb b = fetch(k);
+        lower(b);
         if (b.in) add_A(b.e, b.W, b.m, b.rho);
     }
 #pragma unroll
@@ -1852,8 +1863,7 @@ __device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__
 #pragma unroll
         for (int d = 1; d < N; ++d) beta[d] = (1 / A00) * 0.0;
     }
-    /* rho = sum m_j W (beta . (1, Rij)) (WCXSPH3D.cpp:239-247); a finished particle releases
-     * the neighbours that were waiting for it */
+    /* rho = sum m_j W (beta . (1, Rij)) (WCXSPH3D.cpp:239-247) */
     double rho = 0.0;
     if (lane == 0) {
         double poly = beta[0] + beta[1] * 0.0 + beta[2] * 0.0;
@@ -1865,8 +1875,6 @@ __device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__
         double poly = beta[0] + beta[1] * b.e[1] + beta[2] * b.e[2];
         if (DIM == 3) poly = poly + beta[N - 1] * b.e[N - 1];
         rho += b.m * b.W * poly;
-        /* (a neighbouring rank's particle, at a position >= P.n, is released by its owner) */
-        if (b.idj > me && b.j < P.n && atomicSub(&pend[b.j], 1u) == 1u) release(b.j);
     };
     second(first);
     for (uint32_t k = lane + 64; k < c; k += 64) second(fetch(k));
@@ -1883,46 +1891,39 @@ __global__ __launch_bounds__(REINIT_LEVEL_THREADS) void k_reinit_level(DevParams
                                                             const uint32_t* __restrict__ nbr, uint32_t stride,
                                                             const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
                                                             uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
-                                                            ReinitCtl* __restrict__ ctl) {
-    /* The particles a workgroup sets free are collected in LDS and get their places in the queue
-     * with ONE add to the tail per workgroup: a thousand adds per level to that one word would
-     * queue up at the memory side, and the add leaves each wave's chain of dependent steps. */
+                                                            ReinitCtl* __restrict__ ctl, uint32_t qcap, uint32_t level) {
+    /* The particles a workgroup sets free are collected in LDS and get their places in the next
+     * queue with ONE add to its count per workgroup: a thousand adds per level to that one word
+     * would queue up at the memory side, and the add leaves each wave's chain of dependent steps. */
     constexpr uint32_t ROOM = 2048;
     __shared__ uint32_t s_list[ROOM];
     __shared__ uint32_t s_n, s_base;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const uint32_t begin = ctl->begin, end = ctl->end;
+    const uint32_t cur = level % 3u, nxt = (level + 1u) % 3u;
+    const uint32_t nfront = ctl->cnt[cur];
+    const uint32_t* const front = queue + (size_t)cur * qcap;
+    uint32_t* const next = queue + (size_t)nxt * qcap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->cnt[(level + 2u) % 3u] = 0; /* the queue the next level fills */
+        ctl->done += nfront;
+    }
     const uint32_t lane = threadIdx.x & 63u;
     /* consecutive queue entries go to different workgroups, so a short frontier is spread over
      * the compute units instead of filling the first few */
     const uint32_t wave = (threadIdx.x >> 6) * gridDim.x + blockIdx.x, nwaves = gridDim.x * (REINIT_LEVEL_THREADS / 64);
-    for (uint32_t q = begin + wave; q < end; q += nwaves)
-        reinit_one<DIM>(P, rec, nbr, stride, cnt, id, pend, queue[q], lane, [&](uint32_t j) {
+    for (uint32_t q = wave; q < nfront; q += nwaves)
+        reinit_one<DIM>(P, rec, nbr, stride, cnt, id, pend, front[q], lane, [&](uint32_t j) {
             const uint32_t slot = atomicAdd(&s_n, 1u);
             if (slot < ROOM) s_list[slot] = j;
-            else queue[(uint32_t)atomicAdd((unsigned long long*)&ctl->tail, 1ull)] = j; /* no room left: straight to the queue */
+            else next[atomicAdd(&ctl->cnt[nxt], 1u)] = j; /* no room left: straight to the queue */
         });
     __syncthreads();
     const uint32_t mine = min(s_n, ROOM);
-    /* tail (low word) and ticket (high word) are one 8-byte word: a single add gives the workgroup
-     * its places in the queue and its ticket.  The workgroup that draws the last ticket was the
-     * last to add, so the tail it sees plus its own share is final: it hands the next frontier to
-     * the next launch.  What the level stored (rho, queue entries) is for that launch to read. */
-    __shared__ uint32_t s_last;
-    if (threadIdx.x == 0) {
-        const unsigned long long old =
-            atomicAdd((unsigned long long*)&ctl->tail, (1ull << 32) | (unsigned long long)mine);
-        s_base = (uint32_t)old;
-        s_last = (uint32_t)(old >> 32) == gridDim.x - 1 ? 1u : 0u;
-    }
+    if (mine == 0) return; /* uniform over the workgroup */
+    if (threadIdx.x == 0) s_base = atomicAdd(&ctl->cnt[nxt], mine);
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < mine; t += REINIT_LEVEL_THREADS) queue[s_base + t] = s_list[t];
-    if (threadIdx.x == 0 && s_last) {
-        ctl->ticket = 0;
-        ctl->begin = end;
-        ctl->end = s_base + mine;
-    }
+    for (uint32_t t = threadIdx.x; t < mine; t += REINIT_LEVEL_THREADS) next[s_base + t] = s_list[t];
 }
 
 /* Small cases: the whole walk in ONE workgroup, a workgroup barrier between levels instead of
@@ -1943,8 +1944,9 @@ __global__ __launch_bounds__(REINIT_SINGLE_THREADS) void k_reinit_single(DevPara
     /* and so do the counts of unfinished smaller-index neighbours */
     __shared__ uint32_t s_pend[REINIT_SINGLE_MAX];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = REINIT_SINGLE_THREADS / 64;
-    uint32_t begin = 0, end = ctl->end;
-    if (threadIdx.x == 0) s_tail = end; /* k_reinit_start: end = tail */
+    /* queue 0 holds the first frontier and, behind it, every particle in the order of its release */
+    uint32_t begin = 0, end = ctl->cnt[0];
+    if (threadIdx.x == 0) s_tail = end;
     for (uint32_t t = threadIdx.x; t < P.n; t += REINIT_SINGLE_THREADS) s_pend[t] = pend[t];
     __syncthreads();
     while (begin < end) { /* uniform: every thread holds the same begin and end */
@@ -1959,9 +1961,8 @@ __global__ __launch_bounds__(REINIT_SINGLE_THREADS) void k_reinit_single(DevPara
         end = now;
     }
     if (threadIdx.x == 0) {
-        ctl->begin = begin;
-        ctl->end = begin;
-        ctl->tail = s_tail;
+        ctl->done = begin;
+        ctl->cnt[0] = s_tail;
     }
 }
 
