@@ -68,8 +68,8 @@ struct sph_ctx {
     size_t hist_cap = 0;
     uint32_t* bsum = nullptr;
     size_t bsum_cap = 0;
-    uint32_t *cbeg = nullptr, *cend = nullptr;
-    uint32_t *hbeg = nullptr, *hend = nullptr; /* cell table of the halo particles */
+    uint32_t* cbeg = nullptr; /* cell table: first sorted position with key >= c, ncells + 1 entries */
+    uint32_t* hbeg = nullptr; /* the same for the halo particles */
     size_t cell_cap = 0;
     uint32_t* nbr = nullptr;
     uint32_t cap_k = 0;
@@ -97,7 +97,7 @@ struct sph_ctx {
     bool lists_for_step = false; /* built by the stepping path (wall-wall pairs may be left out) */
     double skin_frac = 0.05, r_list2 = 0, disp_limit = 0;
     uint32_t brick_log2 = 2;
-    uint32_t sub_bits = 0; /* sort-key bits per axis below the cell (SPH_SUB_BITS) */
+    uint32_t run_fine = 4; /* fine cells per cell along the run axis (SPH_RUN_FINE) */
     double disp_host = 0;
     /* The skin follows the motion unless the caller fixed it: step_travel is a running upper
      * estimate of how far the fastest particle gets in one step (the same number on every rank
@@ -311,12 +311,11 @@ int ensure_step_lists(sph_ctx* c, bool* ok);
 /* with_step_lists: the build writes the step lists too (radius r_in2), on the same positions */
 int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below, bool with_step_lists) {
     const uint32_t* hb = c->n_halo ? c->hbeg : nullptr;
-    const uint32_t* he = c->n_halo ? c->hend : nullptr;
     /* positions and wall ids of the owned and the neighbours' particles, packed for the build
      * (in the spare record array, which nothing else uses between a reorder and the next one) */
     const uint32_t m = c->n + c->n_halo;
     hipLaunchKernelGGL(k_fill_pos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, wall_ids(c), m, c->grid, c->dim,
-                       (Pos*)c->rec_alt, cellc_of(c));
+                       c->dp.bound_parts, (Pos*)c->rec_alt, cellc_of(c));
     const Pos* pos = (const Pos*)c->rec_alt;
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
@@ -328,10 +327,10 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below, bool with_step_li
         uint32_t* const tcnt = with_step_lists ? c->cnt_in : nullptr;
         if (c->dim == 3)
             hipLaunchKernelGGL(k_build_list<3>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, pos, c->n, c->grid, c->cbeg,
-                               c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below, hb, he, c->r_in2, tin, tcnt);
+                               c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, c->r_in2, tin, tcnt);
         else
             hipLaunchKernelGGL(k_build_list<2>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, pos, c->n, c->grid, c->cbeg,
-                               c->cend, c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below, hb, he, c->r_in2, tin, tcnt);
+                               c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, c->r_in2, tin, tcnt);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -517,17 +516,15 @@ int exchange_halo_at_rebuild(sph_ctx* c, int src, const double thr[2]) {
     /* sort the halo region by cell */
     launch_hash(c, r + n, m, nullptr, c->keys + n);
     uint32_t *k = c->keys + n, *ka = c->keys_alt + n, *p = c->perm + n, *pa = c->perm_alt + n;
-    const uint32_t sub_all = c->grid.sub * (uint32_t)c->dim;
-    CHK(radix_sort(c, k, ka, p, pa, m, (uint64_t)c->grid.ncells << sub_all));
+    CHK(radix_sort(c, k, ka, p, pa, m, (uint64_t)c->grid.ncells));
     if (k != c->keys + n) HIPCHK(hipMemcpyAsync(c->keys + n, k, (size_t)m * 4, hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(k_reorder_halo, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, p, m, r + n, c->rec_alt + n, c->gid + n,
                        c->gid_alt + n);
     HIPCHK(hipMemcpyAsync(r + n, c->rec_alt + n, (size_t)m * sizeof(Rec), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->gid + n, c->gid_alt + n, (size_t)m * 4, hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(k_halo_pos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, p, m, n, c->halo_pos);
-    HIPCHK(hipMemsetAsync(c->hbeg, 0xFF, sizeof(uint32_t) * c->grid.ncells, c->stream));
-    HIPCHK(hipMemsetAsync(c->hend, 0, sizeof(uint32_t) * c->grid.ncells, c->stream));
-    hipLaunchKernelGGL(k_cell_mark, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, c->keys + n, m, n, c->hbeg, c->hend, sub_all);
+    hipLaunchKernelGGL(k_cell_start, dim3(nblk(c->grid.ncells + 1u)), dim3(SPH_BLOCK), 0, c->stream, c->keys + n, m, n,
+                       c->grid.ncells, c->hbeg);
     HIPCHK(hipGetLastError());
     return SPH_OK;
 }
@@ -723,9 +720,10 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
         if (!(hi[d] >= lo[d])) { lo[d] = 0; hi[d] = 0; } /* no finite particle */
 
     /* Cells of edge >= the candidate radius (plus a relative margin that covers the rounding
-     * of the cell-coordinate arithmetic), in bricks of 2^brick_log2 cells per axis; the grid
-     * is padded to whole bricks.  If a stray particle blew the box up, stretch the cells
-     * until the table fits its allocation. */
+     * of the cell-coordinate arithmetic).  The last axis is the run axis: cut `zf` times finer,
+     * fastest in the sort key (see GridParams); in 3-D the columns are grouped in bricks of
+     * 2^brick_log2 x 2^brick_log2 and the column axes padded to whole bricks.  If a stray
+     * particle blew the box up, stretch the cells until the table fits its allocation. */
     GridParams g;
     memset(&g, 0, sizeof g);
     for (int d = 0; d < 3; ++d) {
@@ -735,26 +733,33 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
         g.nt[d] = 1;
         g.ts[d] = 0;
     }
+    const int run = dim - 1;
+    const uint32_t tbits = dim == 3 ? c->brick_log2 : 0u;
     double edge = r_list * (1.0 + 1e-9);
     uint64_t ncells = 0;
     for (int attempt = 0; attempt < 200; ++attempt) {
         double tot = 1.0;
         for (int d = 0; d < dim; ++d) {
             const double cells = std::floor((hi[d] - lo[d]) / edge) + 1.0;
-            const double tb = (double)(1u << c->brick_log2);
-            tot *= std::ceil(cells / tb) * tb;
+            const double tb = (double)(1u << tbits);
+            tot *= d == run ? cells * c->run_fine : std::ceil(cells / tb) * tb;
         }
-        if (tot <= (double)c->cell_cap && tot < 2147483648.0) {
+        if (tot + 1.0 <= (double)c->cell_cap && tot < 2147483648.0) {
             ncells = 1;
             for (int d = 0; d < dim; ++d) {
                 const double cells = std::floor((hi[d] - lo[d]) / edge) + 1.0;
-                const uint32_t tb = 1u << c->brick_log2;
-                g.ts[d] = c->brick_log2;
-                g.nt[d] = (int)std::ceil(cells / tb);
-                g.n[d] = g.nt[d] * (int)tb;
+                const uint32_t tb = 1u << tbits;
                 g.lo[d] = lo[d];
                 g.inv[d] = 1.0 / edge;
-                ncells *= (uint64_t)g.n[d];
+                if (d == run) {
+                    g.n[d] = (int)cells;
+                    ncells *= (uint64_t)g.n[d] * c->run_fine;
+                } else {
+                    g.ts[d] = tbits;
+                    g.nt[d] = (int)std::ceil(cells / tb);
+                    g.n[d] = g.nt[d] * (int)tb;
+                    ncells *= (uint64_t)g.n[d];
+                }
             }
             break;
         }
@@ -762,16 +767,16 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     }
     if (ncells == 0) return fail(c, SPH_ESTATE, "cell grid exceeds its table");
     g.ncells = (uint32_t)ncells;
-    g.sub = c->sub_bits;
-    while (g.sub > 0 && (((uint64_t)ncells + 1) << (g.sub * (uint32_t)dim)) > (1ull << 32)) --g.sub; /* keys are 32 bits */
+    g.zf = c->run_fine;
+    g.nrun = (uint32_t)g.n[run] * c->run_fine;
+    g.invf = g.inv[run] * (double)c->run_fine;
     c->grid = g;
     /* the draw refers to a particle's cell through a packed word */
     if (g.n[0] > CELLC_MAX_X || g.n[1] > CELLC_MAX_YZ || g.n[2] > CELLC_MAX_YZ) c->two_level = false;
 
     /* sort the owned particles by cell */
     launch_hash(c, c->rec[src], m_sort, drop, c->keys);
-    const uint32_t sub_all = g.sub * (uint32_t)dim;
-    CHK(radix_sort(c, c->keys, c->keys_alt, c->perm, c->perm_alt, m_sort, ((uint64_t)g.ncells + (drop ? 1u : 0u)) << sub_all));
+    CHK(radix_sort(c, c->keys, c->keys_alt, c->perm, c->perm_alt, m_sort, (uint64_t)g.ncells + (drop ? 1u : 0u)));
     /* the leavers sorted behind every cell; from here on this rank owns n particles */
     c->n = n;
     c->dp.n = n;
@@ -848,9 +853,7 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     }
 
     /* cell table of the owned particles */
-    HIPCHK(hipMemsetAsync(c->cbeg, 0xFF, sizeof(uint32_t) * g.ncells, c->stream));
-    HIPCHK(hipMemsetAsync(c->cend, 0, sizeof(uint32_t) * g.ncells, c->stream));
-    hipLaunchKernelGGL(k_cell_mark, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->keys, n, 0u, c->cbeg, c->cend, sub_all);
+    hipLaunchKernelGGL(k_cell_start, dim3(nblk(g.ncells + 1u)), dim3(SPH_BLOCK), 0, c->stream, c->keys, n, 0u, g.ncells, c->cbeg);
     HIPCHK(hipGetLastError());
 
     if (c->dist) {
@@ -858,7 +861,8 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
         /* Owned particles that can see a halo particle, and all those sent to a neighbour, have
          * x <= thr_send[0] or x >= thr_send[1]: with bricks numbered x-slowest they sit in the
          * first / last few brick columns, contiguous ranges of the cell order. */
-        const uint32_t col = ((uint32_t)g.nt[1] * (uint32_t)(dim == 3 ? g.nt[2] : 1)) << (g.ts[0] + g.ts[1] + (dim == 3 ? g.ts[2] : 0));
+        /* keys per column of bricks along x (3-D: a row of bricks, 2-D: one x cell) */
+        const uint32_t col = dim == 3 ? (((uint32_t)g.nt[1]) << (g.ts[0] + g.ts[1])) * g.nrun : g.nrun;
         const uint32_t cols = (uint32_t)g.nt[0];
         auto cellx = [&](double x) {
             double cc = std::floor((x - g.lo[0]) * g.inv[0]);
@@ -868,7 +872,7 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
         };
         const uint32_t colsL = c->has_side[0] ? std::min(cols, (cellx(thr_send[0]) >> g.ts[0]) + 1u) : 0u;
         const uint32_t colR0 = c->has_side[1] ? (cellx(thr_send[1]) >> g.ts[0]) : cols;
-        hipLaunchKernelGGL(k_lower_bounds, dim3(1), dim3(1), 0, c->stream, c->keys, n, (colsL * col) << sub_all, (colR0 * col) << sub_all, c->need + 2);
+        hipLaunchKernelGGL(k_lower_bounds, dim3(1), dim3(1), 0, c->stream, c->keys, n, colsL * col, colR0 * col, c->need + 2);
         HIPCHK(hipMemcpyAsync(c->need_host + 6, c->need + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         c->iL_end = c->has_side[0] ? c->need_host[6] : 0;
@@ -1334,7 +1338,7 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     if (const char* e = getenv("SPH_SKIN_K2")) c->skin_k2 = atof(e);
     c->brick_log2 = c->dim == 3 ? 2u : 3u;
     if (const char* e = getenv("SPH_BRICK_LOG2")) c->brick_log2 = (uint32_t)std::min(5, std::max(0, atoi(e)));
-    if (const char* e = getenv("SPH_SUB_BITS")) c->sub_bits = (uint32_t)std::min(3, std::max(0, atoi(e)));
+    if (const char* e = getenv("SPH_RUN_FINE")) c->run_fine = (uint32_t)std::min(16, std::max(1, atoi(e)));
 
     DevParams& d = c->dp;
     memset(&d, 0, sizeof d);
@@ -1410,7 +1414,6 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     CHK(dalloc(c, &c->perm_alt, n));
     c->cell_cap = std::max<size_t>(8 * n, (size_t)1 << 20);
     CHK(dalloc(c, &c->cbeg, c->cell_cap));
-    CHK(dalloc(c, &c->cend, c->cell_cap));
     c->cap_k = p->max_neighbours > 0 ? (uint32_t)p->max_neighbours : (c->dim == 3 ? 96u : 40u);
     c->cap_k = (c->cap_k + 3u) & ~3u;
     CHK(dalloc(c, &c->nbr, (size_t)c->cap_k * c->own_cap));
@@ -1444,7 +1447,6 @@ int sph_create(const sph_params* p, sph_ctx** out) {
         CHK(dalloc(c, &c->gid, n));
         CHK(dalloc(c, &c->gid_alt, n));
         CHK(dalloc(c, &c->hbeg, c->cell_cap));
-        CHK(dalloc(c, &c->hend, c->cell_cap));
         CHK(dalloc(c, &c->send_idx, 2 * hc));
         CHK(dalloc(c, &c->halo_pos, 2 * hc));
         CHK(dalloc(c, &c->sendbuf, 2 * hc));
@@ -1494,7 +1496,7 @@ void sph_destroy(sph_ctx* c) {
         if (c->pd_alt[q]) (void)hipFree(c->pd_alt[q]);
     }
     void* ptrs[] = {c->pp,   c->pp_alt, c->pRrho, c->pRrho_alt, c->id,       c->id_alt,   c->gid,     c->gid_alt, c->keys,
-                    c->keys_alt, c->perm, c->perm_alt, c->hist, c->bsum,     c->cbeg,     c->cend,    c->hbeg,    c->hend,
+                    c->keys_alt, c->perm, c->perm_alt, c->hist, c->bsum,     c->cbeg,     c->hbeg,
                     c->nbr,  c->cnt,    c->need,  c->S,         c->part,     c->part2,    c->bbox_part, c->tmp,   c->send_idx,
                     c->halo_pos, c->sendbuf, c->recvbuf, c->sendgid, c->recvgid, c->flags, c->fpos,   c->red_dev, c->drop, c->migsend, c->migrecv,
                     c->ri_pend, c->ri_queue, c->ri_ctl, c->nbr_in, c->cnt_in};

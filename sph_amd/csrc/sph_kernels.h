@@ -33,18 +33,17 @@ __device__ __forceinline__ int cell_coord(double x, double lo, double inv, int n
     return (int)c;
 }
 
-/* Cell key.  Cells are grouped into bricks of 2^ts[d] cells per axis; bricks are numbered
- * with x slowest (a slab in x is a contiguous key range) and the cells of one brick are
- * contiguous, so that particles that follow each other in cell order are close in every
- * direction and share most of their neighbours. */
+/* Index of a column of cells (see GridParams): 3-D columns are grouped into bricks of 2^ts[0] x
+ * 2^ts[1], bricks numbered with x slowest; in 2-D the column is the x cell.  The sort key of a
+ * particle is column * nrun + its fine cell along the run axis. */
 template <int DIM>
-__device__ __forceinline__ uint32_t cell_key(const GridParams& g, int cx, int cy, int cz) {
-    const uint32_t ux = (uint32_t)cx, uy = (uint32_t)cy, uz = DIM == 3 ? (uint32_t)cz : 0u;
-    const uint32_t s0 = g.ts[0], s1 = g.ts[1], s2 = DIM == 3 ? g.ts[2] : 0u;
-    uint32_t brick = (ux >> s0) * (uint32_t)g.nt[1] + (uy >> s1);
-    if (DIM == 3) brick = brick * (uint32_t)g.nt[2] + (uz >> s2);
-    const uint32_t local = ((((ux & ((1u << s0) - 1u)) << s1) | (uy & ((1u << s1) - 1u))) << s2) | (uz & ((1u << s2) - 1u));
-    return (brick << (s0 + s1 + s2)) | local;
+__device__ __forceinline__ uint32_t column_index(const GridParams& g, int cx, int cy) {
+    if (DIM == 2) return (uint32_t)cx;
+    const uint32_t ux = (uint32_t)cx, uy = (uint32_t)cy;
+    const uint32_t s0 = g.ts[0], s1 = g.ts[1];
+    const uint32_t brick = (ux >> s0) * (uint32_t)g.nt[1] + (uy >> s1);
+    const uint32_t local = ((ux & ((1u << s0) - 1u)) << s1) | (uy & ((1u << s1) - 1u));
+    return (brick << (s0 + s1)) | local;
 }
 
 /* Workgroups are dealt round-robin to the eight XCDs, each with its own L2.  This maps
@@ -142,31 +141,14 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_hash(const Rec* __restrict__ rec,
                                                     uint32_t* __restrict__ keys) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const uint32_t sub_all = g.sub * (uint32_t)DIM;
     if (drop && drop[i]) { /* handed to a neighbouring slab: sorts behind every cell */
-        keys[i] = g.ncells << sub_all;
+        keys[i] = g.ncells;
         return;
     }
-    const double x = rec[i].xv[0][0], y = rec[i].xv[1][0], z = DIM == 3 ? rec[i].xv[2][0] : 0.0;
-    const int cx = cell_coord(x, g.lo[0], g.inv[0], g.n[0]);
-    const int cy = cell_coord(y, g.lo[1], g.inv[1], g.n[1]);
-    const int cz = DIM == 3 ? cell_coord(z, g.lo[2], g.inv[2], g.n[2]) : 0;
-    /* Below the cell, the particle's place inside it (2^sub parts per axis, x slowest): the
-     * order inside a cell is free, and an order that follows space keeps the particles of a
-     * wave, and what they gather, together however often the cells have been re-sorted. */
-    uint32_t low = 0;
-    if (g.sub) {
-        const double parts = (double)(1u << g.sub);
-        auto part = [&](double v, double lo, double inv, int c) {
-            double f = ((v - lo) * inv - (double)c) * parts;
-            f = fmin(fmax(f, 0.0), parts - 1.0); /* NaN -> 0; particles outside the box sit in edge cells */
-            return (uint32_t)f;
-        };
-        low = part(x, g.lo[0], g.inv[0], cx);
-        low = (low << g.sub) | part(y, g.lo[1], g.inv[1], cy);
-        if (DIM == 3) low = (low << g.sub) | part(z, g.lo[2], g.inv[2], cz);
-    }
-    keys[i] = (cell_key<DIM>(g, cx, cy, cz) << sub_all) | low;
+    const int cx = cell_coord(rec[i].xv[0][0], g.lo[0], g.inv[0], g.n[0]);
+    const int cy = DIM == 3 ? cell_coord(rec[i].xv[1][0], g.lo[1], g.inv[1], g.n[1]) : 0;
+    const int cf = cell_coord(rec[i].xv[DIM - 1][0], g.lo[DIM - 1], g.invf, (int)g.nrun);
+    keys[i] = column_index<DIM>(g, cx, cy) * g.nrun + (uint32_t)cf;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -389,16 +371,20 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reorder(ReorderArgs a) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* cell table: first and one-past-last sorted position of every non-empty cell                */
+/* cell table: cstart[c] = first sorted position whose key is >= c, for c = 0 .. ncells         */
+/* (ncells + 1 entries; the particles of cells a..b are [cstart[a], cstart[b + 1]))            */
 
-__global__ __launch_bounds__(SPH_BLOCK) void k_cell_mark(const uint32_t* __restrict__ keys, uint32_t n,
-                                                         uint32_t index_base, uint32_t* __restrict__ cbeg,
-                                                         uint32_t* __restrict__ cend, uint32_t sub_all) {
-    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = keys[i] >> sub_all; /* the cell; the bits below order the particles inside it */
-    if (i == 0 || (keys[i - 1] >> sub_all) != k) cbeg[k] = index_base + i;
-    if (i == n - 1 || (keys[i + 1] >> sub_all) != k) cend[k] = index_base + i + 1;
+__global__ __launch_bounds__(SPH_BLOCK) void k_cell_start(const uint32_t* __restrict__ keys, uint32_t n,
+                                                          uint32_t index_base, uint32_t ncells,
+                                                          uint32_t* __restrict__ cstart) {
+    const uint32_t c = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (c > ncells) return;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (keys[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    cstart[c] = index_base + lo;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -449,8 +435,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_walls_at_rest(WallRestArgs a, uin
  * <= 2 edges), its square by less than 3e-6 of edge^2; the build keeps d^2 <= (1 + 4e-5) rl^2. */
 struct __attribute__((aligned(16))) Pos {
     float u, v, w;
-    uint32_t id;
+    uint32_t tag; /* bit 31: wall particle; below: the particle's cell along the run axis */
 };
+#define POS_WALL 0x80000000u
 #define LIST_FLOAT_MARGIN 4e-5
 /* The bound above is for cells of the list radius.  When a stray particle has blown the box up
  * the cells are stretched, and the float error grows with the edge: the margin follows it. */
@@ -466,9 +453,10 @@ __device__ __forceinline__ uint32_t pack_cell(int cx, int cy, int cz) {
     return (uint32_t)cx | ((uint32_t)cy << 12) | ((uint32_t)cz << 22);
 }
 
-/* also records every particle's cell (cellc may be null), which k_fill_dpos refers to later */
+/* also records every particle's cell (cellc may be null), which k_fill_dpos refers to later;
+ * `id` is the array the wall test reads (particles below bound_parts are wall particles) */
 __global__ __launch_bounds__(SPH_BLOCK) void k_fill_pos(const Rec* __restrict__ rec, const uint32_t* __restrict__ id, uint32_t m,
-                                                        GridParams g, int dim, Pos* __restrict__ pos,
+                                                        GridParams g, int dim, uint32_t bound_parts, Pos* __restrict__ pos,
                                                         uint32_t* __restrict__ cellc) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= m) return;
@@ -480,7 +468,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_fill_pos(const Rec* __restrict__ 
     p.u = (float)((x - g.lo[0]) - (double)cx * (1.0 / g.inv[0]));
     p.v = (float)((y - g.lo[1]) - (double)cy * (1.0 / g.inv[1]));
     p.w = dim == 3 ? (float)((z - g.lo[2]) - (double)cz * (1.0 / g.inv[2])) : 0.0f;
-    p.id = id[i];
+    p.tag = (uint32_t)(dim == 3 ? cz : cy) | (id[i] < bound_parts ? POS_WALL : 0u);
     pos[i] = p;
     if (cellc) cellc[i] = pack_cell(cx, cy, cz);
 }
@@ -570,62 +558,73 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_draw_lists(const DPos* __restrict
     if (active && q == 0) cnt_out[i] = k;
 }
 
-/* Four lanes per particle: the quad walks each neighbouring cell four candidates at a time and
- * appends the keepers in lane order, so a row lists its candidates cell by cell (x-slowest
- * offsets), own particles before halo particles, ascending position within a cell. */
+/* Four lanes per particle.  For every neighbouring column of cells (9 in 3-D, 3 in 2-D) the
+ * quad reads ONE range of the cell table: the fine cells along the run axis that a sphere of
+ * the list radius around the particle can reach in that column (none if the column itself is
+ * out of reach), own particles and, in a slab run, the neighbours' particles.  It tests the
+ * range eight candidates at a time (two per lane, both fetches in flight together) and appends
+ * the keepers in ascending order, so a row lists its candidates column by column (x slowest),
+ * own particles before halo particles, ascending along the run axis. */
 template <int DIM>
 __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict__ rec, const Pos* __restrict__ pos, uint32_t n,
                                                           GridParams g,
-                                                          const uint32_t* __restrict__ cbeg,
-                                                          const uint32_t* __restrict__ cend, double rl2,
+                                                          const uint32_t* __restrict__ cstart, double rl2,
                                                           uint32_t* __restrict__ nbr, uint32_t stride, uint32_t cap,
                                                           uint32_t* __restrict__ cnt, uint32_t* __restrict__ need,
-                                                          uint32_t wall_below, const uint32_t* __restrict__ hbeg,
-                                                          const uint32_t* __restrict__ hend, double rin2,
-                                                          uint32_t* __restrict__ nbr_in, uint32_t* __restrict__ cnt_in) {
+                                                          int prune_walls, const uint32_t* __restrict__ hstart,
+                                                          double rin2, uint32_t* __restrict__ nbr_in,
+                                                          uint32_t* __restrict__ cnt_in) {
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
     const uint32_t i_raw = xcd_contiguous_block() * (SPH_BLOCK / 4) + (threadIdx.x >> 2);
     const bool active = i_raw < n;
     const uint32_t i = active ? i_raw : n - 1;
-    /* wall_below > 0: pairs of two wall particles are left out (see k_walls_at_rest) */
+    /* prune_walls: pairs of two wall particles are left out (see k_walls_at_rest) */
     const Pos pi = pos[i];
-    const bool i_wall = pi.id < wall_below;
+    const bool i_wall = prune_walls && (pi.tag & POS_WALL);
+    const int crun_i = (int)(pi.tag & ~POS_WALL);
     const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
-    const float edge = (float)(1.0 / g.inv[0]); /* all axes share one edge */
-    const float rl2f = (float)(rl2 * (1.0 + list_float_margin(1.0 / g.inv[0], sqrt(rl2))));
+    const double run_i = DIM == 3 ? zi : yi;
+    const double edge_d = 1.0 / g.inv[0]; /* all axes share one edge */
+    const float edge = (float)edge_d;
+    const double margin = list_float_margin(edge_d, sqrt(rl2));
+    const float rl2f = (float)(rl2 * (1.0 + margin));
     const int cx = cell_coord(xi, g.lo[0], g.inv[0], g.n[0]);
-    const int cy = cell_coord(yi, g.lo[1], g.inv[1], g.n[1]);
-    const int cz = DIM == 3 ? cell_coord(zi, g.lo[2], g.inv[2], g.n[2]) : 0;
+    const int cy = DIM == 3 ? cell_coord(yi, g.lo[1], g.inv[1], g.n[1]) : 0;
     uint32_t* const row = nbr + (size_t)i * stride;
     /* nbr_in != nullptr: the step lists (the candidates within the smaller radius rin2, same
      * order) are written as well, which saves the draw that would follow the rebuild */
     uint32_t* const row_in = nbr_in ? nbr_in + (size_t)i * stride : nullptr;
-    const float rin2f = (float)(rin2 * (1.0 + list_float_margin(1.0 / g.inv[0], sqrt(rl2))));
-    uint32_t k_in = 0;
-    /* A neighbouring cell is skipped when even its nearest point is out of reach.  Distances in
-     * cell edges: fx is the particle's place inside its cell, the gap to a cell on the low side
-     * is fx, on the high side 1 - fx (never negative, and the bound carries a margin far above
-     * the rounding of fx, so no candidate is lost; a kept cell is tested entry by entry as before). */
+    const float rin2f = (float)(rin2 * (1.0 + margin));
+    /* The particle's place inside its cell, in cell edges: the gap to a column on the low side
+     * is fx, on the high side 1 - fx (never negative).  What a column can hold within reach lies
+     * within sqrt(rl^2 - gap^2) of the particle along the run axis; the bound carries a margin
+     * far above the rounding of fx and of the square root, so no candidate is lost. */
     const double fx = fmin(fmax((xi - g.lo[0]) * g.inv[0] - (double)cx, 0.0), 1.0);
-    const double fy = fmin(fmax((yi - g.lo[1]) * g.inv[1] - (double)cy, 0.0), 1.0);
-    const double fz = DIM == 3 ? fmin(fmax((zi - g.lo[2]) * g.inv[2] - (double)cz, 0.0), 1.0) : 0.0;
-    const double reach2 = rl2 * g.inv[0] * g.inv[0] * (1.0 + 1e-6); /* all axes share one edge */
-    uint32_t k = 0;
-    /* The quad tests the particles [b, e) eight at a time (two per lane, both fetches in flight
-     * together) and appends the keepers in ascending order.  Empty range: b = 0xFFFFFFFF, e = 0. */
-    auto walk = [&](uint32_t b, uint32_t e, float bx, float by, float bz) {
+    const double fy = DIM == 3 ? fmin(fmax((yi - g.lo[1]) * g.inv[1] - (double)cy, 0.0), 1.0) : 0.0;
+    const double reach2 = rl2 * g.inv[0] * g.inv[0] * (1.0 + 1e-6);
+    const uint32_t below = (1u << q) - 1u;
+    uint32_t k = 0, k_in = 0;
+    /* candidates [b, e) of a column whose cells are (dx, dy) away from the particle's */
+    auto walk = [&](uint32_t b, uint32_t e, float bx, float by) {
         for (uint32_t j0 = b; j0 < e; j0 += 8) {
             const uint32_t ja = j0 + q, jb = j0 + 4u + q;
             const Pos pa = pos[ja < e ? ja : i], pb = pos[jb < e ? jb : i]; /* whole entries, no second fetch */
-            const float ax_ = bx - pa.u, ay_ = by - pa.v, az_ = DIM == 3 ? bz - pa.w : 0.0f;
-            const float cx_ = bx - pb.u, cy_ = by - pb.v, cz_ = DIM == 3 ? bz - pb.w : 0.0f;
+            /* along the run axis the two particles may be several cells apart */
+            const float ra = (float)(crun_i - (int)(pa.tag & ~POS_WALL)) * edge, rb = (float)(crun_i - (int)(pb.tag & ~POS_WALL)) * edge;
+            float ax_, ay_, az_, cx_, cy_, cz_;
+            if (DIM == 3) {
+                ax_ = bx - pa.u; ay_ = by - pa.v; az_ = ra + (pi.w - pa.w);
+                cx_ = bx - pb.u; cy_ = by - pb.v; cz_ = rb + (pi.w - pb.w);
+            } else {
+                ax_ = bx - pa.u; ay_ = ra + (pi.v - pa.v); az_ = 0.0f;
+                cx_ = bx - pb.u; cy_ = rb + (pi.v - pb.v); cz_ = 0.0f;
+            }
             const float d2a = ax_ * ax_ + ay_ * ay_ + az_ * az_;
             const float d2b = cx_ * cx_ + cy_ * cy_ + cz_ * cz_;
-            const bool keepa = active & (ja < e) & (ja != i) & (d2a <= rl2f) & !(i_wall & (pa.id < wall_below));
-            const bool keepb = active & (jb < e) & (jb != i) & (d2b <= rl2f) & !(i_wall & (pb.id < wall_below));
+            const bool keepa = active & (ja < e) & (ja != i) & (d2a <= rl2f) & !(i_wall & ((pa.tag & POS_WALL) != 0u));
+            const bool keepb = active & (jb < e) & (jb != i) & (d2b <= rl2f) & !(i_wall & ((pb.tag & POS_WALL) != 0u));
             const uint32_t bitsa = (uint32_t)(__ballot(keepa) >> (lane & 60u)) & 0xFu;
             const uint32_t bitsb = (uint32_t)(__ballot(keepb) >> (lane & 60u)) & 0xFu;
-            const uint32_t below = (1u << q) - 1u;
             const uint32_t ata = k + __popc(bitsa & below);
             const uint32_t atb = k + __popc(bitsa) + __popc(bitsb & below);
             if (keepa && ata < cap) row[ata] = ja;
@@ -643,43 +642,40 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
             }
         }
     };
-    /* per x-layer of cells: the cell-table entries of its 9 (3) cells are requested together,
-     * then the cells are walked; a cell is left out when even its nearest point is out of reach */
-    constexpr int NYZ = DIM == 3 ? 9 : 3;
-    for (int dx = -1; dx <= 1; ++dx) {
-        const int ax = cx + dx;
-        if (ax < 0 || ax >= g.n[0]) continue;
+    /* the table entries of all neighbouring columns are requested together, then the ranges are walked */
+    constexpr int NCOL = DIM == 3 ? 9 : 3;
+    uint32_t cb[NCOL], ce[NCOL], qb[NCOL], qe[NCOL];
+#pragma unroll
+    for (int t = 0; t < NCOL; ++t) {
+        const int dx = DIM == 3 ? t / 3 - 1 : t - 1, dy = DIM == 3 ? t % 3 - 1 : 0;
+        const int ax = cx + dx, ay = cy + dy;
         const double gx = dx < 0 ? fx : (dx > 0 ? 1.0 - fx : 0.0);
+        const double gy = dy < 0 ? fy : (dy > 0 ? 1.0 - fy : 0.0);
+        const double gap2 = gx * gx + gy * gy; /* in cell edges */
+        const bool take = ax >= 0 && ax < g.n[0] && (DIM != 3 || (ay >= 0 && ay < g.n[1])) && !(gap2 > reach2);
+        /* half-width of the reachable stretch of the column along the run axis */
+        const double hw = sqrt(fmax(reach2 - gap2, 0.0)) * edge_d * (1.0 + 1e-6) + 1e-9 * edge_d;
+        const uint32_t fa = (uint32_t)cell_coord(run_i - hw, g.lo[DIM - 1], g.invf, (int)g.nrun);
+        const uint32_t fb = (uint32_t)cell_coord(run_i + hw, g.lo[DIM - 1], g.invf, (int)g.nrun);
+        const uint32_t base = take ? column_index<DIM>(g, ax, ay) * g.nrun : 0u; /* column 0 always exists */
+        const uint32_t b0 = cstart[base + fa], e0 = cstart[base + fb + 1u];
+        cb[t] = take ? b0 : 0xFFFFFFFFu;
+        ce[t] = take ? e0 : 0u;
+        if (hstart) {
+            const uint32_t b1 = hstart[base + fa], e1 = hstart[base + fb + 1u];
+            qb[t] = take ? b1 : 0xFFFFFFFFu;
+            qe[t] = take ? e1 : 0u;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NCOL; ++t) {
+        const int dx = DIM == 3 ? t / 3 - 1 : t - 1, dy = DIM == 3 ? t % 3 - 1 : 0;
         /* x_i - x_j = (u_i - dx*edge) - u_j for a candidate dx cells away */
         const float bx = pi.u - (float)dx * edge;
-        uint32_t cb[NYZ], ce[NYZ], qb[NYZ], qe[NYZ];
-#pragma unroll
-        for (int t = 0; t < NYZ; ++t) {
-            const int dy = DIM == 3 ? t / 3 - 1 : t - 1, dz = DIM == 3 ? t % 3 - 1 : 0;
-            const int ay = cy + dy, az = cz + dz;
-            const double gy = dy < 0 ? fy : (dy > 0 ? 1.0 - fy : 0.0);
-            const double gz = dz < 0 ? fz : (dz > 0 ? 1.0 - fz : 0.0);
-            const bool take = ay >= 0 && ay < g.n[1] && (DIM != 3 || (az >= 0 && az < g.n[2])) &&
-                              !(gx * gx + gy * gy + gz * gz > reach2);
-            const uint32_t c = take ? cell_key<DIM>(g, ax, ay, az) : 0u; /* cell 0 always exists */
-            const uint32_t b0 = cbeg[c], e0 = cend[c];
-            cb[t] = take ? b0 : 0xFFFFFFFFu;
-            ce[t] = take ? e0 : 0u;
-            if (hbeg) {
-                const uint32_t b1 = hbeg[c], e1 = hend[c];
-                qb[t] = take ? b1 : 0xFFFFFFFFu;
-                qe[t] = take ? e1 : 0u;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NYZ; ++t) {
-            const int dy = DIM == 3 ? t / 3 - 1 : t - 1, dz = DIM == 3 ? t % 3 - 1 : 0;
-            const float by = pi.v - (float)dy * edge;
-            const float bz = DIM == 3 ? pi.w - (float)dz * edge : 0.0f;
-            /* own particles of the cell, then (slab runs) the neighbours' particles in it */
-            walk(cb[t], ce[t], bx, by, bz);
-            if (hbeg) walk(qb[t], qe[t], bx, by, bz);
-        }
+        const float by = pi.v - (float)dy * edge;
+        /* own particles of the range, then (slab runs) the neighbours' particles in it */
+        walk(cb[t], ce[t], bx, by);
+        if (hstart) walk(qb[t], qe[t], bx, by);
     }
     if (active && q == 0) {
         cnt[i] = k < cap ? k : cap;

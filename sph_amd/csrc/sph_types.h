@@ -34,15 +34,24 @@ struct DevParams {
     double   gconst;    /* 5*(1/HSQ)*correc: the gradient's constant factor (WCXSPH3D.cpp:135) */
 };
 
-/* Uniform grid over the particles' bounding box. Cell edge >= candidate radius. */
+/* Uniform grid over the particles' bounding box, cell edge >= candidate radius, and the order
+ * the particles are sorted into.  The last axis (z in 3-D, y in 2-D) is the RUN axis: cells are
+ * cut `zf` times finer along it and are the fastest-varying part of the sort key, so that the
+ * particles of one column of cells (one cell across in the other axes) are contiguous and
+ * sorted along the run axis.  A neighbour query then reads ONE contiguous range per
+ * neighbouring column -- the part of the column that can be within reach -- instead of three
+ * whole cells.  In 3-D the columns themselves are grouped in bricks of 2^ts x 2^ts columns,
+ * bricks numbered with x slowest (a slab in x is a contiguous key range). */
 struct GridParams {
     double   lo[3];
-    double   inv[3];
-    int32_t  n[3];    /* cells per axis, a multiple of the brick edge */
-    int32_t  nt[3];   /* bricks per axis */
-    uint32_t ts[3];   /* log2 of the brick edge in cells */
-    uint32_t ncells;
-    uint32_t sub;     /* sort-key bits below the cell: the particle's place inside its cell, per axis */
+    double   inv[3];  /* 1 / cell edge (all axes share one edge) */
+    int32_t  n[3];    /* cells per axis; the column axes padded to whole bricks */
+    int32_t  nt[3];   /* bricks per column axis */
+    uint32_t ts[3];   /* log2 of the brick edge in cells, column axes */
+    uint32_t ncells;  /* columns * nrun: the sort key's range */
+    uint32_t zf;      /* fine cells per cell along the run axis */
+    uint32_t nrun;    /* fine cells per column = n[run axis] * zf */
+    double   invf;    /* 1 / fine cell edge */
 };
 
 /* Device-resident run state: the reference's file-scope globals (WCXSPH3D.cpp:70-79) plus
