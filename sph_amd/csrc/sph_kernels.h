@@ -819,8 +819,9 @@ __device__ unsigned long long g_phase[8];
  *  quad together -- lane q loads bytes 16q..16q+15 of each -- so one wave instruction
  *  touches 16 records of 64 contiguous bytes instead of 64 scattered 16-byte pieces (the
  *  vector memory pipe is paced by distinct segments per instruction).  The pieces are
- *  exchanged through a per-wave LDS area: written lane-linear, read back one whole record
- *  per lane.  The loads of round t+1 are in flight during the arithmetic of round t.  Pairs with
+ *  exchanged through a per-wave LDS area: copied there lane-linear straight from memory
+ *  (global->LDS loads, no register stop), read back one whole record per lane.  The copies
+ *  of round t+1 are in flight during the arithmetic of round t.  Pairs with
  *  dist2_exact < search_radius contribute momentum, continuity, XSPH and max(mu); the four
  *  partial sums of a quad are added at the end.
  *
@@ -907,24 +908,27 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
     double Vs0 = 0.0, Vs1 = 0.0, Vs2 = 0.0;
     double rr = 0.0, mumax = 0.0;
 
-    /* the four pieces this lane holds of the next round's records */
-    uint4 pc0, pc1, pc2, pc3;
     /* While the record array is smaller than 4 GiB (!WIDE) a 32-bit byte offset from its base
      * addresses any piece: one shift-or per load instead of 64-bit arithmetic. */
     const uint32_t qoff = 16u * (uint32_t)q;
+    /* The pieces go from memory into the transpose area without a stop in registers: a 16-byte
+     * global->LDS copy, every lane naming its own source, the destination the wave-uniform base
+     * plus lane*16 -- the lane-linear image the transpose reads.  The copies of round t+1 are
+     * issued once round t's records have been read out of the area (lgkmcnt) and are waited for
+     * (vmcnt) a whole round of arithmetic later. */
+    auto piece = [&](uint32_t j) -> const char* {
+        return !WIDE ? (const char*)rin + ((j << 6) | qoff) : (const char*)(rin + j) + 16 * q;
+    };
+    auto copy16 = [&](const char* src, char* dst_wave_base) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+    };
     auto load4 = [&](uint32_t j0, uint32_t j1, uint32_t j2, uint32_t j3) {
-        if (!WIDE) {
-            const char* const base = (const char*)rin;
-            pc0 = *(const uint4*)(base + ((j0 << 6) | qoff));
-            pc1 = *(const uint4*)(base + ((j1 << 6) | qoff));
-            pc2 = *(const uint4*)(base + ((j2 << 6) | qoff));
-            pc3 = *(const uint4*)(base + ((j3 << 6) | qoff));
-            return;
-        }
-        pc0 = *(const uint4*)((const char*)(rin + j0) + 16 * q);
-        pc1 = *(const uint4*)((const char*)(rin + j1) + 16 * q);
-        pc2 = *(const uint4*)((const char*)(rin + j2) + 16 * q);
-        pc3 = *(const uint4*)((const char*)(rin + j3) + 16 * q);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the area has been read */
+        copy16(piece(j0), wstage);
+        copy16(piece(j1), wstage + 1 * PAIR_LDS_BLOCK + 16);
+        copy16(piece(j2), wstage + 2 * PAIR_LDS_BLOCK + 32);
+        copy16(piece(j3), wstage + 3 * PAIR_LDS_BLOCK + 48);
     };
     /* load round t, whose four candidates sit in lane (t & 3) of the quad */
 #define LOAD_FROM(VEC, R, T)                                                        \
@@ -937,17 +941,9 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
          * cleared when allocated); what is fetched for them is never used */                   \
         load4(a0, a1, a2, a3);                                                                  \
     }
-    char* const my_slot = wstage + lane * 16;
     auto exchange = [&]() -> Rec {
-        *(uint4*)(my_slot) = pc0;
-        *(uint4*)(my_slot + 1 * PAIR_LDS_BLOCK + 16) = pc1;
-        *(uint4*)(my_slot + 2 * PAIR_LDS_BLOCK + 32) = pc2;
-        *(uint4*)(my_slot + 3 * PAIR_LDS_BLOCK + 48) = pc3;
-        /* lanes of one wave run in lockstep and the LDS keeps a wave's accesses in order;
-         * only the compiler has to be kept from moving the read above the writes */
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        /* the copies left a round ago; the vector-memory counter also covers them */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return *(const Rec*)(wstage + q * PAIR_LDS_BLOCK + q * 16 + (lane >> 2) * 64);
     };
 
@@ -1030,8 +1026,9 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
         const uint32_t nsup = (rounds + 3u) >> 2;
         for (uint32_t u = 0; u < nsup; ++u) {
             uint4 vafter = vnext;
-            if (u + 2 < nsup) vafter = fetch_vec(u + 2);
             ROUND(0, vcur, 1)
+            /* behind round 1's copies, so a round old at the next wait */
+            if (u + 2 < nsup) vafter = fetch_vec(u + 2);
             ROUND(1, vcur, 2)
             ROUND(2, vcur, 3)
             ROUND(3, vnext, 0)
