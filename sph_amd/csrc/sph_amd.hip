@@ -7,6 +7,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <thread>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -125,6 +127,10 @@ struct sph_ctx {
     /* DensityReinit: dependency counters, frontier queue, control block (allocated on first use) */
     uint32_t *ri_pend = nullptr, *ri_queue = nullptr;
     ReinitCtl* ri_ctl = nullptr;
+    uint32_t* ri_flow = nullptr; /* control words of the one-launch walk */
+    uint32_t ri_owners = 0;      /* its workgroups (all resident at once); 0 = walk by levels */
+    uint32_t ri_gen = 0;         /* its calls so far: the tag of the densities a call publishes */
+    double ri_limit_s = 30.0;    /* a wave of it gives up after waiting this long for one particle */
     uint64_t reinit_launches = 0;
     uint64_t reinit_rounds = 0; /* slab runs: exchanges of the last density re-initialisation */
 
@@ -1499,7 +1505,7 @@ void sph_destroy(sph_ctx* c) {
                     c->keys_alt, c->perm, c->perm_alt, c->hist, c->bsum,     c->cbeg,     c->hbeg,
                     c->nbr,  c->cnt,    c->need,  c->S,         c->part,     c->part2,    c->bbox_part, c->tmp,   c->send_idx,
                     c->halo_pos, c->sendbuf, c->recvbuf, c->sendgid, c->recvgid, c->flags, c->fpos,   c->red_dev, c->drop, c->migsend, c->migrecv,
-                    c->ri_pend, c->ri_queue, c->ri_ctl, c->nbr_in, c->cnt_in};
+                    c->ri_pend, c->ri_queue, c->ri_ctl, c->ri_flow, c->nbr_in, c->cnt_in};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->S_host) (void)hipHostFree(c->S_host);
@@ -1740,18 +1746,12 @@ int sph_set_dt(sph_ctx* c, double dt) {
     return SPH_OK;
 }
 
-int sph_density_reinit(sph_ctx* c) {
-    if (!c) return SPH_EINVAL;
-    if (!c->uploaded_np1) return fail(c, SPH_ESTATE, "state was never uploaded");
-    HIPCHK(hipSetDevice(c->device));
-    if (!c->ri_pend) {
-        CHK(dalloc(c, &c->ri_pend, c->cap));
-        CHK(dalloc(c, &c->ri_queue, (size_t)3 * c->cap)); /* three frontier queues used in turn */
-        CHK(dalloc(c, &c->ri_ctl, 1));
-    }
-    /* complete lists (wall-wall pairs included) on the positions of state n+1; a slab run
-     * fetches its neighbours' particles with them */
-    CHK(rebuild(c, c->b0));
+namespace {
+
+/* The walk of DensityReinit over lists that are already built; `one_launch` picks the one-launch
+ * walk (a single rank's large case).  *stalled: that walk gave up with all its waves gone. */
+int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
+    *stalled = false;
     const uint32_t n = c->n;
     const uint32_t qcap = c->cap;
     Rec* r = c->rec[c->b0];
@@ -1767,12 +1767,22 @@ int sph_density_reinit(sph_ctx* c) {
         ++level;                                                                                                          \
     } while (0)
     uint32_t* touches = c->dist ? c->flags : nullptr;
+    /* a single rank's large case is walked in one launch: every workgroup a queue of its own */
+    const uint32_t owners = one_launch ? c->ri_owners : 0u;
+    const uint32_t qseg = owners ? (n + owners - 1) / owners + 1u : 0u;
+    if (owners) {
+        if ((size_t)owners * qseg + 2 + 2 * (size_t)n > (size_t)3 * c->cap + 1024)
+            return fail(c, SPH_ESTATE, "density re-initialisation: queues do not fit");
+        ++c->ri_gen;
+        HIPCHK(hipMemsetAsync(c->ri_queue, 0xFF, sizeof(uint32_t) * (size_t)owners * qseg, c->stream));
+        HIPCHK(hipMemsetAsync(c->ri_flow, 0, sizeof(uint32_t) * REINIT_FLOW_WORDS(owners), c->stream));
+    }
     if (c->dim == 3)
         hipLaunchKernelGGL(k_reinit_count<3>, dim3((n + SPH_BLOCK / 4 - 1) / (SPH_BLOCK / 4)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k, c->cnt,
-                           ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches);
+                           ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches, owners, qseg, c->ri_flow);
     else
         hipLaunchKernelGGL(k_reinit_count<2>, dim3((n + SPH_BLOCK / 4 - 1) / (SPH_BLOCK / 4)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k, c->cnt,
-                           ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches);
+                           ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches, owners, qseg, c->ri_flow);
     HIPCHK(hipGetLastError());
     ReinitCtl* h = (ReinitCtl*)c->need_host; /* pinned, 8 words */
     if (c->dist) {
@@ -1846,6 +1856,49 @@ int sph_density_reinit(sph_ctx* c) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (h->done != n || h->cnt[0] != n)
             return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
+    } else if (owners) {
+        const uint64_t limit = (uint64_t)(c->ri_limit_s * 1e8); /* ticks of the 100 MHz clock */
+        unsigned long long* const gran = (unsigned long long*)(c->ri_queue + (((size_t)owners * qseg + 1) & ~(size_t)1));
+        if (c->dim == 3)
+            hipLaunchKernelGGL(k_reinit_flow<3>, dim3(owners), dim3(REINIT_FLOW_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
+                               c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, qseg, limit, gran, c->ri_gen);
+        else
+            hipLaunchKernelGGL(k_reinit_flow<2>, dim3(owners), dim3(REINIT_FLOW_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
+                               c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, qseg, limit, gran, c->ri_gen);
+        HIPCHK(hipGetLastError());
+        ++c->reinit_launches;
+        if (c->trace) fprintf(stderr, "[sph] reinit: one-launch walk, %u workgroups, %u places each, call %u\n", owners, qseg, c->ri_gen);
+        HIPCHK(hipMemcpyAsync(h, c->ri_flow, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        {
+            /* the waves give up by themselves after `limit`; should the launch outlive that by far,
+             * the host raises the stop flag from a second stream */
+            const auto t_start = std::chrono::steady_clock::now();
+            bool raised = false;
+            for (;;) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) HIPCHK(q);
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+                if (!raised && waited > 2.0 * c->ri_limit_s + 5.0) {
+                    hipStream_t side;
+                    HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+                    static const uint32_t one = 1;
+                    HIPCHK(hipMemcpyAsync(c->ri_flow, &one, sizeof one, hipMemcpyHostToDevice, side));
+                    HIPCHK(hipStreamSynchronize(side));
+                    HIPCHK(hipStreamDestroy(side));
+                    raised = true;
+                    fprintf(stderr, "[sph] density re-initialisation: stop flag raised by the host after %.1f s\n", waited);
+                }
+                if (waited > 4.0 * c->ri_limit_s + 20.0)
+                    return fail(c, SPH_ESTATE, "density re-initialisation does not come back; the context is lost");
+                if (waited > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (*(const uint32_t*)h != 0) {
+            *stalled = true; /* every wave has left: the caller may walk again, by levels */
+            return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
+        }
     } else {
         /* one launch per dependency level; the host looks at the queues every so often */
         const int batch = 256, grid = 256; /* one wavefront per released particle, 4096 per pass of the grid */
@@ -1863,6 +1916,58 @@ int sph_density_reinit(sph_ctx* c) {
         }
     }
 #undef RI_LEVEL
+    return SPH_OK;
+}
+
+}  // namespace
+
+int sph_density_reinit(sph_ctx* c) {
+    if (!c) return SPH_EINVAL;
+    if (!c->uploaded_np1) return fail(c, SPH_ESTATE, "state was never uploaded");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->ri_pend) {
+        CHK(dalloc(c, &c->ri_pend, c->cap));
+        /* three frontier queues used in turn (walk by levels); the one-launch walk keeps its
+         * queues (n + a few places) and behind them 8 bytes per particle of published densities */
+        CHK(dalloc(c, &c->ri_queue, (size_t)3 * c->cap + 1024));
+        HIPCHK(hipMemsetAsync(c->ri_queue, 0, sizeof(uint32_t) * ((size_t)3 * c->cap + 1024), c->stream));
+        CHK(dalloc(c, &c->ri_ctl, 1));
+        /* the one-launch walk needs all its workgroups on the chip together */
+        int per_cu = 0;
+        const void* fn = c->dim == 3 ? (const void*)k_reinit_flow<3> : (const void*)k_reinit_flow<2>;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, REINIT_FLOW_THREADS, 0));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, c->device));
+        c->ri_owners = per_cu > 0 ? (uint32_t)std::min(256, prop.multiProcessorCount) : 0u;
+        if (const char* e = getenv("SPH_REINIT_WALK")) {
+            if (!strcmp(e, "levels")) c->ri_owners = 0;
+        }
+        if (const char* e = getenv("SPH_REINIT_LIMIT_S")) c->ri_limit_s = std::max(1e-6, atof(e));
+        if (c->ri_owners) CHK(dalloc(c, &c->ri_flow, REINIT_FLOW_WORDS(c->ri_owners)));
+    }
+    /* complete lists (wall-wall pairs included) on the positions of state n+1; a slab run
+     * fetches its neighbours' particles with them */
+    CHK(rebuild(c, c->b0));
+    const uint32_t n = c->n;
+    Rec* r = c->rec[c->b0];
+    bool stalled = false;
+    if (!c->dist && n > REINIT_SINGLE_MAX && c->ri_owners) {
+        /* The one-launch walk needs every one of its workgroups on the chip at once.  Should it
+         * give up (compute units taken by somebody else's work), rho goes back to what it was
+         * and this context walks by levels from now on. */
+        float* const keep = (float*)c->tmp;
+        hipLaunchKernelGGL(k_rho_copy, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, r, keep, n, 0);
+        const int rc = reinit_walk(c, true, &stalled);
+        if (rc != SPH_OK && !stalled) return rc;
+        if (stalled) {
+            fprintf(stderr, "[sph] density re-initialisation: the one-launch walk gave up; walking by levels\n");
+            hipLaunchKernelGGL(k_rho_copy, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, r, keep, n, 1);
+            c->ri_owners = 0;
+            CHK(reinit_walk(c, false, &stalled));
+        }
+    } else {
+        CHK(reinit_walk(c, false, &stalled));
+    }
     /* p/rho^2 of the records follows the new rho (Forces forms it from p and rho, WCXSPH3D.cpp:180) */
     hipLaunchKernelGGL(k_fix_prr, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, r, c->pp, n);
     HIPCHK(hipGetLastError());

@@ -1662,6 +1662,12 @@ __device__ __forceinline__ bool fullpiv_solve_e0(double (&lu)[N][N], double (&be
  * inside the radius with a smaller original index */
 #define REINIT_DONE 0x80000000u
 
+/* The one-launch walk (k_reinit_flow) keeps one queue per workgroup; its control words: word 0 is
+ * the stop flag, the tail of queue o sits 64 bytes apart from the others */
+#define REINIT_FLOW_TAIL(o) (16u * (1u + (o)))
+#define REINIT_FLOW_WORDS(owners) (16u * (1u + (owners)))
+#define REINIT_EMPTY 0xFFFFFFFFu
+
 /* pend[i] = number of neighbours inside the radius with a smaller original index; particles
  * with none form the first frontier.  Slab runs (touches != nullptr): `id` holds global
  * indices, neighbours at positions >= P.n are the adjacent ranks' particles, and touches[i]
@@ -1671,7 +1677,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_count(DevParams P, const R
                                                             const uint32_t* __restrict__ nbr, uint32_t stride,
                                                             const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
                                                             uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
-                                                            ReinitCtl* __restrict__ ctl, uint32_t* __restrict__ touches) {
+                                                            ReinitCtl* __restrict__ ctl, uint32_t* __restrict__ touches,
+                                                            uint32_t owners, uint32_t qseg, uint32_t* __restrict__ flow) {
     /* four lanes per particle, each taking every fourth candidate */
     const uint32_t i_raw = blockIdx.x * (SPH_BLOCK / 4) + (threadIdx.x >> 2), q = threadIdx.x & 3u;
     const bool active = i_raw < P.n;
@@ -1694,7 +1701,13 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_count(DevParams P, const R
     if (!active || q != 0) return;
     pend[i] = lower;
     if (touches) touches[i] = far;
-    if (lower == 0) queue[atomicAdd(&ctl->cnt[0], 1u)] = i; /* the first frontier: queue 0 */
+    if (lower != 0) return;
+    if (owners) { /* one-launch walk: into the queue of the workgroup that owns particle i */
+        const uint32_t o = i % owners;
+        queue[(size_t)o * qseg + atomicAdd(flow + REINIT_FLOW_TAIL(o), 1u)] = i;
+    } else {
+        queue[atomicAdd(&ctl->cnt[0], 1u)] = i; /* the first frontier: queue 0 */
+    }
 }
 
 /* Slab runs, between two local walks: what the neighbours report of their particles that this
@@ -1759,15 +1772,31 @@ __device__ __forceinline__ double wave_allsum(double v) {
     return v;
 }
 
+/* What the one-launch walk hands to reinit_one: where finished particles publish their rho
+ * ({rho, tag} in one 8-byte word, tag = the number of this DensityReinit call), the stop flag
+ * and how long a wave may wait. */
+struct ReinitFlow {
+    unsigned long long* gran;
+    uint32_t* stop;
+    uint32_t gen;
+    uint64_t limit;
+};
+
 /* DensityReinit of one released particle by one wavefront: the lanes share out its candidates,
  * partial sums are folded with a fixed butterfly (every lane ends with the same bits), every
  * lane solves the small system, lane 0 stores rho, and each lane tells `release` about the
- * waiting neighbours among its candidates whose last dependency this was. */
-template <int DIM, typename Release>
-__device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__ rec, const uint32_t* __restrict__ nbr,
+ * waiting neighbours among its candidates whose last dependency this was.
+ *   FLOW (the one-launch walk): a particle is released when its last smaller-index neighbour
+ * is BEGUN, not finished, so that its wave has the lists, records and kernel weights in hand by
+ * the time the neighbours' densities arrive; it then waits for the tagged rho of each of them.
+ * Every particle it waits for is in the hands of a running wave (it was begun), and of those the
+ * one with the smallest index waits for nobody: the walk cannot lock up.  Returns false when
+ * the wave gave up (stop flag or time limit). */
+template <int DIM, bool FLOW, typename Release>
+__device__ __forceinline__ bool reinit_one(const DevParams& P, Rec* __restrict__ rec, const uint32_t* __restrict__ nbr,
                                            uint32_t stride, const uint32_t* __restrict__ cnt,
                                            const uint32_t* __restrict__ id, uint32_t* __restrict__ pend, uint32_t i,
-                                           uint32_t lane, Release release) {
+                                           uint32_t lane, Release release, const ReinitFlow fl = ReinitFlow()) {
     constexpr int N = DIM + 1;
     /* this lane's first candidate is requested together with the particle's own data, and its
      * record before the count is known (entries past the count are stale but index the arrays):
@@ -1819,16 +1848,48 @@ __device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__
                                        : b.e[1] * b.e[1] + b.e[2] * b.e[2]);
         b.W = w2_kernel(P, r);
         b.m = P.xsph ? (double)rj.m : P.mass;
-        b.rho = (double)rj.rho;
+        b.rho = (double)rj.rho; /* FLOW: the old value; right for the neighbours with a larger index */
         return b;
     };
     auto fetch = [&](uint32_t k) { return fetch_j(nbr[(size_t)i * stride + k]); };
-    /* A finished particle releases the neighbours that were waiting for it.  Which ones is
-     * known as soon as the candidates are in, and whoever reads this particle's new rho does so
-     * after the level's end (a kernel boundary, or the workgroup barrier of the one-workgroup
-     * walk): the counters are lowered now, so that the atomics' round trips and the queueing run
-     * beside the sums and the solve instead of after them.  (A neighbouring rank's particle,
-     * at a position >= P.n, is released by its owner.) */
+    /* FLOW: the new rho of the in-radius neighbours with a smaller index, as soon as each is
+     * published (a device-scope load goes past whatever the caches hold).  Every branch below
+     * is on a value made wave-uniform by hand, and the loop has one way out. */
+    auto uniform = [](bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; };
+    auto settle = [&](Nb& b) -> bool {
+        const bool need = b.in && b.idj < me;
+        unsigned long long g = need ? __hip_atomic_load(fl.gran + b.j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        bool miss = need && (uint32_t)(g >> 32) != fl.gen;
+        bool wait = uniform(__ballot(miss) != 0ull);
+        bool ok = true;
+        if (wait) {
+            const uint64_t t0 = wall_clock64();
+            uint32_t spins = 0;
+            while (wait) {
+                __builtin_amdgcn_s_sleep(1);
+                if (miss) g = __hip_atomic_load(fl.gran + b.j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                miss = need && (uint32_t)(g >> 32) != fl.gen;
+                wait = uniform(__ballot(miss) != 0ull);
+                if (uniform((++spins & 63u) == 0u)) {
+                    const bool stop = uniform(__hip_atomic_load(fl.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+                    const bool late = uniform(wall_clock64() - t0 > fl.limit);
+                    if (late && lane == 0) __hip_atomic_store(fl.stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (stop || late) {
+                        ok = false;
+                        wait = false;
+                    }
+                }
+            }
+        }
+        if (need) b.rho = (double)__uint_as_float((uint32_t)g);
+        return uniform(ok);
+    };
+    /* A particle releases the neighbours that were waiting for it.  Which ones is known as soon
+     * as the candidates are in, and whoever reads this particle's new rho does so after the
+     * level's end (a kernel boundary, or the workgroup barrier of the one-workgroup walk) or, in
+     * the one-launch walk, waits for its tag: the counters are lowered now, so that the atomics'
+     * round trips and the queueing run beside the sums and the solve instead of after them.  (A
+     * neighbouring rank's particle, at a position >= P.n, is released by its owner.) */
     auto lower = [&](const Nb& b) {
         if (b.in && b.idj > me && b.j < P.n && atomicSub(&pend[b.j], 1u) == 1u) release(b.j);
     };
@@ -1836,10 +1897,22 @@ __device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__
     Nb first = fetch_j(j_first);
     first.in = first.in && lane < c;
     lower(first);
+    bool ok = true; /* wave-uniform; FLOW only: false once a wait has been given up */
+    if (FLOW) {
+        /* beyond 64 candidates: release first, then wait */
+        for (uint32_t k = lane + 64; k < c; k += 64) lower(fetch(k));
+        ok = settle(first);
+    }
     if (first.in) add_A(first.e, first.W, first.m, first.rho);
-    for (uint32_t k = lane + 64; k < c; k += 64) {
-        const Nb b = fetch(k);
-        lower(b);
+    for (uint32_t k0 = 64; k0 < c; k0 += 64) { /* wave-uniform trip count */
+        const uint32_t k = k0 + lane;
+        Nb b = fetch(min(k, c - 1u));
+        b.in = b.in && k < c;
+        if (FLOW) {
+            if (ok) ok = settle(b);
+        } else {
+            lower(b);
+        }
         if (b.in) add_A(b.e, b.W, b.m, b.rho);
     }
 #pragma unroll
@@ -1870,12 +1943,23 @@ __device__ __forceinline__ void reinit_one(const DevParams& P, Rec* __restrict__
         rho += b.m * b.W * poly;
     };
     second(first);
-    for (uint32_t k = lane + 64; k < c; k += 64) second(fetch(k));
-    rho = wave_allsum(rho);
-    if (lane == 0) {
-        rec[i].rho = (float)rho;
-        pend[i] = REINIT_DONE;
+    for (uint32_t k0 = 64; k0 < c; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        Nb b = fetch(min(k, c - 1u));
+        b.in = b.in && k < c;
+        if (FLOW && ok) ok = settle(b); /* published long ago: no wait */
+        second(b);
     }
+    rho = wave_allsum(rho);
+    if (lane == 0 && ok) { /* a given-up particle's numbers are not stored */
+        rec[i].rho = (float)rho;
+        if (FLOW) /* rho and tag in one store that goes through to memory */
+            __hip_atomic_store(fl.gran + i, ((unsigned long long)fl.gen << 32) | __float_as_uint((float)rho), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        else
+            pend[i] = REINIT_DONE;
+    }
+    return ok;
 }
 
 #define REINIT_LEVEL_THREADS 1024 /* 256 workgroups of 16 waves: a frontier of 4096 particles in one pass */
@@ -1906,7 +1990,7 @@ __global__ __launch_bounds__(REINIT_LEVEL_THREADS) void k_reinit_level(DevParams
      * the compute units instead of filling the first few */
     const uint32_t wave = (threadIdx.x >> 6) * gridDim.x + blockIdx.x, nwaves = gridDim.x * (REINIT_LEVEL_THREADS / 64);
     for (uint32_t q = wave; q < nfront; q += nwaves)
-        reinit_one<DIM>(P, rec, nbr, stride, cnt, id, pend, front[q], lane, [&](uint32_t j) {
+        reinit_one<DIM, false>(P, rec, nbr, stride, cnt, id, pend, front[q], lane, [&](uint32_t j) {
             const uint32_t slot = atomicAdd(&s_n, 1u);
             if (slot < ROOM) s_list[slot] = j;
             else next[atomicAdd(&ctl->cnt[nxt], 1u)] = j; /* no room left: straight to the queue */
@@ -1917,6 +2001,84 @@ __global__ __launch_bounds__(REINIT_LEVEL_THREADS) void k_reinit_level(DevParams
     if (threadIdx.x == 0) s_base = atomicAdd(&ctl->cnt[nxt], mine);
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < mine; t += REINIT_LEVEL_THREADS) next[s_base + t] = s_list[t];
+}
+
+/* The whole walk in ONE launch, without levels: workgroup o owns the particles i with
+ * i % gridDim.x == o and works through its own queue, which holds them in the order of their
+ * release.  A wave claims the next place of its queue, waits until a particle shows up there
+ * and re-initialises it (reinit_one, FLOW): it lowers the counters of the waiting neighbours at
+ * once -- the one whose count reaches zero goes into its owner's queue -- gathers its own sums'
+ * ingredients, waits for the published rho of its smaller-index neighbours and publishes its own.
+ * A hop of the dependency chain costs one hand-over of 8 bytes through memory plus the sums and
+ * the solve; the lists, records, counters and queues of the next particles are dealt with
+ * meanwhile by other waves.
+ *   Every workgroup must be resident (the host sizes the grid by the occupancy query).  Every
+ * wave leaves: when its queue's places are used up (a workgroup knows how many particles it
+ * owns), when the stop flag is up, or when it has waited `limit` ticks of the 100 MHz clock
+ * for one thing (it raises the flag; the host reports the walk as stalled). */
+#define REINIT_FLOW_THREADS 1024
+template <int DIM>
+__global__ __launch_bounds__(REINIT_FLOW_THREADS) void k_reinit_flow(DevParams P, Rec* __restrict__ rec,
+                                                                     const uint32_t* __restrict__ nbr, uint32_t stride,
+                                                                     const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
+                                                                     uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
+                                                                     uint32_t* __restrict__ flow, uint32_t qseg, uint64_t limit,
+                                                                     unsigned long long* __restrict__ gran, uint32_t gen) {
+    __shared__ uint32_t s_head;
+    const uint32_t o = blockIdx.x, owners = gridDim.x;
+    const uint32_t mine = P.n > o ? (P.n - o + owners - 1u) / owners : 0u;
+    if (threadIdx.x == 0) s_head = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t* const myq = queue + (size_t)o * qseg;
+    ReinitFlow fl;
+    fl.gran = gran;
+    fl.stop = flow;
+    fl.gen = gen;
+    fl.limit = limit;
+    /* every branch is on a value made wave-uniform by hand; the loops have one way out */
+    auto uniform = [](bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; };
+    bool run = true;
+    while (run) {
+        uint32_t h = 0;
+        if (lane == 0) h = atomicAdd(&s_head, 1u);
+        h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+        run = uniform(h < mine);
+        if (!run) continue;
+        const uint64_t t0 = wall_clock64();
+        uint32_t i = REINIT_EMPTY, spins = 0;
+        bool waiting = true;
+        while (waiting) {
+            i = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(myq + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            waiting = uniform(i == REINIT_EMPTY);
+            if (waiting) {
+                __builtin_amdgcn_s_sleep(4);
+                if (uniform((++spins & 15u) == 0u)) {
+                    const bool stop = uniform(__hip_atomic_load(flow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+                    const bool late = uniform(wall_clock64() - t0 > limit);
+                    if (late && lane == 0) __hip_atomic_store(flow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (stop || late) {
+                        run = false;
+                        waiting = false;
+                    }
+                }
+            }
+        }
+        if (!run) continue;
+        run = reinit_one<DIM, true>(P, rec, nbr, stride, cnt, id, pend, i, lane, [&](uint32_t j) {
+            const uint32_t own = j % owners;
+            const uint32_t slot = atomicAdd(flow + REINIT_FLOW_TAIL(own), 1u);
+            __hip_atomic_store(queue + (size_t)own * qseg + slot, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }, fl);
+    }
+}
+
+/* rho of the records to a plain array (back = 0) or back from it (back = 1) */
+__global__ __launch_bounds__(SPH_BLOCK) void k_rho_copy(Rec* __restrict__ rec, float* __restrict__ keep, uint32_t n, int back) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (back) rec[i].rho = keep[i];
+    else keep[i] = rec[i].rho;
 }
 
 /* Small cases: the whole walk in ONE workgroup, a workgroup barrier between levels instead of
@@ -1944,7 +2106,7 @@ __global__ __launch_bounds__(REINIT_SINGLE_THREADS) void k_reinit_single(DevPara
     __syncthreads();
     while (begin < end) { /* uniform: every thread holds the same begin and end */
         for (uint32_t q = begin + wave; q < end; q += nwaves)
-            reinit_one<DIM>(P, rec, nbr, stride, cnt, id, s_pend, queue[q], lane,
+            reinit_one<DIM, false>(P, rec, nbr, stride, cnt, id, s_pend, queue[q], lane,
                             [&](uint32_t j) { queue[atomicAdd(&s_tail, 1u)] = j; });
         __threadfence_block();
         __syncthreads();

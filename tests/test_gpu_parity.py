@@ -387,7 +387,7 @@ def test_frames_with_density_reinit(name):
     dict(program=2, npart=(24, 20, 16), pstep=0.1, box=(3.0, 2.4, 2.2), start=(0.15, 0.15, 0.15)),
 ], ids=["2d_20k", "3d_22k"])
 def test_density_reinit_beyond_the_one_workgroup_size(spec):
-    # cases of up to 12288 particles are walked by one workgroup; larger ones by one launch per level
+    # cases of up to 12288 particles are walked by one workgroup; larger ones by a grid of workgroups in one launch
     orc, sim = start(spec)
     assert orc.npts > 16384
     orc.step(4)
@@ -397,6 +397,32 @@ def test_density_reinit_beyond_the_one_workgroup_size(spec):
     g, o = sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1)
     assert util.float_ulp_diff(g["rho"], o["rho"]).max() <= 1
     sim.close()
+
+
+def test_density_reinit_in_one_launch_and_by_levels_give_the_same_bits(monkeypatch, capfd):
+    # a single rank's large case is walked in one launch (every particle as soon as the neighbours
+    # before it are done); slab runs walk level by level.  Same sums in the same order: same bits.
+    # Third run: the one-launch walk is made to give up (its waves may wait 20 us for anything);
+    # rho is put back and the walk is done by levels.
+    spec = dict(program=2, npart=(64, 48, 24), pstep=0.1, box=(13.0, 5.1, 4.8), start=(0.15, 0.15, 0.15))
+    rho = {}
+    for walk, limit in (("flow", "30"), ("levels", "30"), ("flow", "2e-5")):
+        monkeypatch.setenv("SPH_REINIT_WALK", walk)
+        monkeypatch.setenv("SPH_REINIT_LIMIT_S", limit)
+        _, pc = util.both_cases(spec)
+        sim = capi.Sim.from_case(pc)
+        sim.forces(capi.STATE_N)
+        sim.zero_boundary_forces(capi.STATE_N)
+        sim.step(30)
+        for _ in range(2):
+            sim.density_reinit()
+        rho[walk, limit] = sim.download(capi.STATE_NP1)["rho"].copy()
+        assert sim.npts > 100000
+        sim.close()
+    assert "gave up; walking by levels" in capfd.readouterr().err
+    want = rho["levels", "30"].view(np.int32)
+    assert np.array_equal(rho["flow", "30"].view(np.int32), want)
+    assert np.array_equal(rho["flow", "2e-5"].view(np.int32), want)
 
 
 def test_density_reinit_on_a_uniform_lattice_keeps_rho0_inside():
