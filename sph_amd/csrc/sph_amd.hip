@@ -690,7 +690,11 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     }
     c->two_level = for_step && c->inner_mode >= 0 && c->inner_frac < c->skin_frac &&
                    (c->inner_mode == 1 || c->skin_frac >= c->two_level_min_skin);
-    const double r_list = std::sqrt(c->prm.search_radius_sq) * (1.0 + c->skin_frac);
+    /* lists that serve one evaluation on these very positions (Forces at t = 0, DensityReinit, the
+     * neighbour probe) need no room for travel: the skin that the stepping path has grown in
+     * developed flow would only make their rows 2-3 times longer */
+    const double skin_here = for_step ? c->skin_frac : std::min(c->skin_frac, 0.01);
+    const double r_list = std::sqrt(c->prm.search_radius_sq) * (1.0 + skin_here);
     const double reach = r_list * (1.0 + 1e-6); /* halo selection distance beyond a neighbour's extent */
     double thr_send[2] = {0, 0};
     if (c->dist) {
@@ -915,7 +919,7 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     ++c->rebuilds;
     if (c->trace)
         fprintf(stderr, "[sph] rebuild %llu: n %u skin %.4f two_level %d inner %.5f step_travel/R %.5f in_travel/R %.3e rows %u\n",
-                (unsigned long long)c->rebuilds, c->n, c->skin_frac, (int)c->two_level, c->inner_frac,
+                (unsigned long long)c->rebuilds, c->n, skin_here, (int)c->two_level, c->inner_frac,
                 c->step_travel / std::sqrt(c->prm.search_radius_sq), c->in_travel / std::sqrt(c->prm.search_radius_sq), c->cap_k);
     if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
     return SPH_OK;

@@ -1754,6 +1754,68 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_rescan(DevParams P, const 
     if (lower == 0) queue[(size_t)(level % 3u) * qcap + atomicAdd(&ctl->cnt[level % 3u], 1u)] = i;
 }
 
+/* x + (x moved by W lanes to its partner block), W = 16 or 32, for a double */
+template <int W>
+__device__ __forceinline__ double rows_pair_sum(double x) {
+    const uint32_t lo = (uint32_t)__double2loint(x), hi = (uint32_t)__double2hiint(x);
+    if (W == 16) {
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
+/* Ten wave-wide sums at once (the upper triangle of the 3-D moment matrix): instead of ten
+ * butterflies of six steps, every step folds PAIRS of values, each keeping its half of the lanes
+ * -- the sum of a in the lower half, of b in the upper -- so the work halves with the lane
+ * span: 13 additions and 30 moves instead of 60 and 120.  Rows of 32 and 16 lanes are exchanged
+ * by the row-swap instructions, 8 and 4 lanes by DPP moves written into half of the banks, the
+ * last two steps inside a quad.  The totals end up in fixed lanes and are read from there, so
+ * every lane gets the same bits; the order of additions is fixed. */
+template <int CTRL, int BANKS>
+__device__ __forceinline__ double dpp_into_banks(double keep, double from) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(from), CTRL, 0xF, BANKS, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(from), CTRL, 0xF, BANKS, false);
+    return __hiloint2double(hi, lo);
+}
+template <int W>
+__device__ __forceinline__ double rows_fold_pair(double a, double b) { /* a's sum in the even blocks of W lanes, b's in the odd */
+    const uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
+    const uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+    if (W == 16) {
+        const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+    const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ void wave_allsum10(double (&v)[10]) {
+    /* 32: lanes 0-31 keep the first of a pair, lanes 32-63 the second */
+    const double w0 = rows_fold_pair<32>(v[0], v[1]), w1 = rows_fold_pair<32>(v[2], v[3]), w2 = rows_fold_pair<32>(v[4], v[5]),
+                 w3 = rows_fold_pair<32>(v[6], v[7]), w4 = rows_fold_pair<32>(v[8], v[9]);
+    /* 16: rows of sixteen now hold, in turn, v0 v2 v1 v3 | v4 v6 v5 v7 | v8 v8 v9 v9 */
+    const double x0 = rows_fold_pair<16>(w0, w1), x1 = rows_fold_pair<16>(w2, w3), x2 = rows_fold_pair<16>(w4, w4);
+    /* 8: lanes 0-7 of a row keep x0, lanes 8-15 x1 (a rotation by eight inside the row) */
+    const double y0 = dpp_into_banks<0x128, 0xC>(x0, x1) + dpp_into_banks<0x128, 0x3>(x1, x0);
+    const double y1 = x2 + dpp_into_banks<0x128, 0xF>(x2, x2);
+    /* 4: quads 0 and 2 of a row keep y0, quads 1 and 3 y1 (shifts by four lanes) */
+    double z = dpp_into_banks<0x114, 0xA>(y0, y1) + dpp_into_banks<0x104, 0x5>(y1, y0);
+    z += quad_perm_d<QP_XOR2>(z);
+    z += quad_perm_d<QP_XOR1>(z);
+    /* row r = 0..3: quad 0 holds (v0 v2 v1 v3)[r], quad 2 (v4 v6 v5 v7)[r], quads 1 and 3 (v8 v8 v9 v9)[r] */
+    v[0] = lane_value(z, 0);  v[2] = lane_value(z, 16); v[1] = lane_value(z, 32); v[3] = lane_value(z, 48);
+    v[4] = lane_value(z, 8);  v[6] = lane_value(z, 24); v[5] = lane_value(z, 40); v[7] = lane_value(z, 56);
+    v[8] = lane_value(z, 4);  v[9] = lane_value(z, 36);
+}
+
 /* One wavefront per released particle: the lanes share out its candidates, partial sums are
  * folded with a fixed butterfly (every lane ends with the same bits), every lane solves the
  * small system, lane 0 stores rho, and each lane releases the waiting neighbours among its
@@ -1767,8 +1829,11 @@ __device__ __forceinline__ double wave_allsum(double v) {
     v += quad_perm_d<QP_XOR2>(v);
     v += quad_perm_d<0x141>(v); /* row_half_mirror */
     v += quad_perm_d<0x140>(v); /* row_mirror */
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+    /* across the four rows: swap the odd rows of one copy with the even rows of another (vector
+     * ALU, no trip through the LDS crossbar); the two copies then hold, lane by lane, the two
+     * rows to be added -- the same two numbers as a shuffle by 16, then by 32, would pair */
+    v = rows_pair_sum<16>(v);
+    v = rows_pair_sum<32>(v);
     return v;
 }
 
@@ -1810,28 +1875,39 @@ __device__ __forceinline__ bool reinit_one(const DevParams& P, Rec* __restrict__
     for (int r = 0; r < N; ++r)
 #pragma unroll
         for (int cc = 0; cc < N; ++cc) A[r][cc] = 0.0;
-    auto add_A = [&](const double (&e)[N], double W, double mj, double rhoj) {
+    /* one neighbour's share of Abar is W * abar * m_j / rho_j (WCXSPH3D.cpp:226-228): everything
+     * but the division is formed when the neighbour's record is read -- in the one-launch walk
+     * that is before its new rho has arrived */
+    auto share_of = [&](const double (&e)[N], double W, double mj, double (&num)[N][N]) {
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll
             for (int cc = r; cc < N; ++cc) {
                 const double abar = r == 0 ? e[cc] : e[cc] * e[r];
-                A[r][cc] += W * abar * mj / rhoj;
+                num[r][cc] = W * abar * mj;
             }
+    };
+    auto add_A = [&](const double (&num)[N][N], double rhoj) {
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int cc = r; cc < N; ++cc) A[r][cc] += num[r][cc] / rhoj;
     };
     if (lane == 0) { /* the particle itself (distance 0) */
         double e[N];
         e[0] = 1;
 #pragma unroll
         for (int d = 0; d < DIM; ++d) e[d + 1] = 0.0;
-        add_A(e, w2_kernel(P, 0.0), P.xsph ? (double)ri.m : P.mass, (double)ri.rho);
+        double num[N][N];
+        share_of(e, w2_kernel(P, 0.0), P.xsph ? (double)ri.m : P.mass, num);
+        add_A(num, (double)ri.rho);
     }
     /* one candidate of the list: in the radius by the search's own distance (xj - xi, as the
      * search forms it)?  then Rij = xi - xj, W(|Rij|), m_j, rho_j */
     struct Nb {
         uint32_t j, idj;
         bool in;
-        double e[N], W, m, rho;
+        double e[N], mW, rho, num[N][N];
     };
     auto fetch_j = [&](uint32_t j) {
         Nb b;
@@ -1846,9 +1922,19 @@ __device__ __forceinline__ bool reinit_one(const DevParams& P, Rec* __restrict__
         for (int d = 0; d < DIM; ++d) b.e[d + 1] = ri.xv[d][0] - rj.xv[d][0];
         const double r = sqrt(DIM == 3 ? b.e[1] * b.e[1] + b.e[2] * b.e[2] + b.e[N - 1] * b.e[N - 1]
                                        : b.e[1] * b.e[1] + b.e[2] * b.e[2]);
-        b.W = w2_kernel(P, r);
-        b.m = P.xsph ? (double)rj.m : P.mass;
+        const double W = w2_kernel(P, r), m = P.xsph ? (double)rj.m : P.mass;
+        share_of(b.e, W, m, b.num);
+        b.mW = m * W;
         b.rho = (double)rj.rho; /* FLOW: the old value; right for the neighbours with a larger index */
+        if (FLOW) { /* have all of this in registers before any waiting starts */
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+#pragma unroll
+                for (int cc = r; cc < N; ++cc) asm volatile("" ::"v"(b.num[r][cc]));
+#pragma unroll
+            for (int d = 1; d < N; ++d) asm volatile("" ::"v"(b.e[d]));
+            asm volatile("" ::"v"(b.mW));
+        }
         return b;
     };
     auto fetch = [&](uint32_t k) { return fetch_j(nbr[(size_t)i * stride + k]); };
@@ -1903,7 +1989,7 @@ __device__ __forceinline__ bool reinit_one(const DevParams& P, Rec* __restrict__
         for (uint32_t k = lane + 64; k < c; k += 64) lower(fetch(k));
         ok = settle(first);
     }
-    if (first.in) add_A(first.e, first.W, first.m, first.rho);
+    if (first.in) add_A(first.num, first.rho);
     for (uint32_t k0 = 64; k0 < c; k0 += 64) { /* wave-uniform trip count */
         const uint32_t k = k0 + lane;
         Nb b = fetch(min(k, c - 1u));
@@ -1913,15 +1999,28 @@ __device__ __forceinline__ bool reinit_one(const DevParams& P, Rec* __restrict__
         } else {
             lower(b);
         }
-        if (b.in) add_A(b.e, b.W, b.m, b.rho);
+        if (b.in) add_A(b.num, b.rho);
     }
+    if constexpr (N == 4) {
+        double t[10] = {A[0][0], A[0][1], A[0][2], A[0][3], A[1][1], A[1][2], A[1][3], A[2][2], A[2][3], A[3][3]};
+        wave_allsum10(t);
+        int q = 0;
 #pragma unroll
-    for (int r = 0; r < N; ++r)
+        for (int r = 0; r < N; ++r)
 #pragma unroll
-        for (int cc = r; cc < N; ++cc) {
-            A[r][cc] = wave_allsum(A[r][cc]);
-            A[cc][r] = A[r][cc];
-        }
+            for (int cc = r; cc < N; ++cc) {
+                A[r][cc] = t[q++];
+                A[cc][r] = A[r][cc];
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int cc = r; cc < N; ++cc) {
+                A[r][cc] = wave_allsum(A[r][cc]);
+                A[cc][r] = A[r][cc];
+            }
+    }
     const double A00 = A[0][0];
     double beta[N];
     if (!fullpiv_solve_e0<N>(A, beta)) { /* Shepard fallback (WCXSPH3D.cpp:235-236) */
@@ -1940,7 +2039,7 @@ __device__ __forceinline__ bool reinit_one(const DevParams& P, Rec* __restrict__
         if (!b.in) return;
         double poly = beta[0] + beta[1] * b.e[1] + beta[2] * b.e[2];
         if (DIM == 3) poly = poly + beta[N - 1] * b.e[N - 1];
-        rho += b.m * b.W * poly;
+        rho += b.mW * poly;
     };
     second(first);
     for (uint32_t k0 = 64; k0 < c; k0 += 64) {
