@@ -162,7 +162,10 @@ int sph_set_dt(sph_ctx* ctx, double dt);
 /* DensityReinit(particlesh, tree) (WCXSPH3D.cpp:208-249; WCXSPH.cpp:204-243; WCSPH.cpp:203-243):
  * rho of state n+1 in the reference's order, a particle seeing the new rho of its neighbours
  * with a smaller index.  On a slab-decomposed context the call is collective (every rank makes
- * it) and the order is that of the global indices. */
+ * it) and the order is that of the global indices.  A single-domain context of more than 12 288
+ * particles is walked in one launch that needs the whole GPU (all its workgroups resident); if
+ * the GPU does not grant that the call restores rho and walks one launch per dependency level
+ * instead -- same values (environment: SPH_REINIT_WALK=levels, SPH_REINIT_LIMIT_S). */
 int sph_density_reinit(sph_ctx* ctx);
 
 /* The fixed-radius neighbour sets that Forces() would see for one state, as CSR over
