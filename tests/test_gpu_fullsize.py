@@ -199,6 +199,15 @@ def _one_step_against_the_oracle(spec, what, min_particles):
     go, gc = sim.neighbours(capi.STATE_NP1)
     oo, occ = orc.neighbours(O.STATE_NP1)
     assert np.array_equal(go, oo) and np.array_equal(gc, occ), what + ": neighbour sets after the step"
+    # DensityReinit on the stepped state (WCXSPH3D.cpp:208-249): at this size the whole walk is one
+    # launch; rho within one float ulp of the oracle's sequential walk, nothing else touched
+    orc.density_reinit()
+    sim.density_reinit()
+    g2, o2 = sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1)
+    u = util.float_ulp_diff(g2["rho"], o2["rho"])
+    print("%s: DensityReinit rho max ulp %d, differing %d of %d" % (what, u.max(), int((u > 0).sum()), len(u)))
+    assert u.max() <= 1, what + ": DensityReinit"
+    assert np.array_equal(g2["x"], g["x"]) and np.array_equal(g2["p"].view(np.int32), g["p"].view(np.int32))
     sim.close()
     orc.close()
 
