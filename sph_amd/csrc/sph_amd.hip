@@ -130,7 +130,7 @@ struct sph_ctx {
     uint32_t* ri_flow = nullptr; /* control words of the one-launch walk */
     uint32_t ri_owners = 0;      /* its workgroups (all resident at once); 0 = walk by levels */
     uint32_t ri_gen = 0;         /* its calls so far: the tag of the densities a call publishes */
-    double ri_limit_s = 30.0;    /* a wave of it gives up after waiting this long for one particle */
+    double ri_limit_s = 10.0;    /* a wave of it gives up after waiting this long for one thing (a whole walk takes < 1 s) */
     uint64_t reinit_launches = 0;
     uint64_t reinit_rounds = 0; /* slab runs: exchanges of the last density re-initialisation */
 
