@@ -693,7 +693,9 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     /* lists that serve one evaluation on these very positions (Forces at t = 0, DensityReinit, the
      * neighbour probe) need no room for travel: the skin that the stepping path has grown in
      * developed flow would only make their rows 2-3 times longer */
-    const double skin_here = for_step ? c->skin_frac : std::min(c->skin_frac, 0.01);
+    double skin_here = for_step ? c->skin_frac : std::min(c->skin_frac, 0.01);
+    if (!for_step)
+        if (const char* e = getenv("SPH_ONESHOT_SKIN")) skin_here = std::max(0.0, atof(e)); /* tests: long rows */
     const double r_list = std::sqrt(c->prm.search_radius_sq) * (1.0 + skin_here);
     const double reach = r_list * (1.0 + 1e-6); /* halo selection distance beyond a neighbour's extent */
     double thr_send[2] = {0, 0};

@@ -425,6 +425,25 @@ def test_density_reinit_in_one_launch_and_by_levels_give_the_same_bits(monkeypat
     assert np.array_equal(rho["flow", "2e-5"].view(np.int32), want)
 
 
+@pytest.mark.parametrize("walk", ["flow", "levels"])
+def test_density_reinit_with_rows_of_more_than_64_candidates(walk, monkeypatch):
+    # a wavefront takes 64 candidates of a row at a time; lists with a wide skin make rows longer
+    # than that (a second pass over the row, in the one-launch walk with its own waits)
+    monkeypatch.setenv("SPH_ONESHOT_SKIN", "0.9")
+    monkeypatch.setenv("SPH_REINIT_WALK", walk)
+    spec = dict(program=2, npart=(24, 20, 16), pstep=0.1, box=(3.0, 2.4, 2.2), start=(0.15, 0.15, 0.15))
+    orc, sim = start(spec)
+    orc.step(6)
+    sim.step(6)
+    orc.density_reinit()
+    sim.density_reinit()
+    g, o = sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1)
+    u = util.float_ulp_diff(g["rho"], o["rho"])
+    print("rows beyond 64 (%s): rho max ulp %d, differing %d of %d" % (walk, u.max(), int((u > 0).sum()), len(u)))
+    assert u.max() <= 1
+    sim.close()
+
+
 def test_density_reinit_on_a_uniform_lattice_keeps_rho0_inside():
     # known answer: MLS reproduces a constant field wherever the moment matrix is invertible
     _, pc = util.both_cases(CASES["wcxsph3d_block"])
