@@ -1572,13 +1572,39 @@ __device__ __forceinline__ bool fullpiv_solve_e0(double (&lu)[N][N], double (&be
         if (stopped) continue;
         int br = kk, bc = kk;
         double biggest = -1.0;
+        /* First pivot of a SYMMETRIC matrix (the callers' moment matrices are, bit for bit): when
+         * the largest diagonal entry exceeds every entry above the diagonal, the scan below would
+         * pick the first diagonal entry of that size; ten comparisons instead of sixteen
+         * compare-and-select steps.  Wave-uniform like everything here. */
+        bool found = false;
+        if (kk == 0) {
+            double d = fabs(lu[0][0]), o = 0.0;
+            int di = 0;
 #pragma unroll
-        for (int c = kk; c < N; ++c)
-#pragma unroll
-            for (int r = kk; r < N; ++r) {
-                const double a = fabs(lu[r][c]);
-                if (a > biggest) { biggest = a; br = r; bc = c; }
+            for (int t = 1; t < N; ++t) {
+                const double a = fabs(lu[t][t]);
+                if (a > d) { d = a; di = t; }
             }
+#pragma unroll
+            for (int c = 1; c < N; ++c)
+#pragma unroll
+                for (int r = 0; r < c; ++r) o = fmax(o, fabs(lu[r][c]));
+            if (__builtin_amdgcn_readfirstlane((int)(o < d)) != 0) { /* false for NaN entries too */
+                found = true;
+                biggest = d;
+                br = di;
+                bc = di;
+            }
+        }
+        if (!found) {
+#pragma unroll
+            for (int c = kk; c < N; ++c)
+#pragma unroll
+                for (int r = kk; r < N; ++r) {
+                    const double a = fabs(lu[r][c]);
+                    if (a > biggest) { biggest = a; br = r; bc = c; }
+                }
+        }
         if (biggest == 0.0) {
             nonzero = kk;
             stopped = true;
@@ -1588,25 +1614,33 @@ __device__ __forceinline__ bool fullpiv_solve_e0(double (&lu)[N][N], double (&be
         rowT[kk] = br;
         colT[kk] = bc;
         /* the transpositions as selects over fixed places (a branch on the pivot's row or column
-         * would be merged into an indexed access, and the matrix would leave the registers) */
+         * would be merged into an indexed access, and the matrix would leave the registers).  Every
+         * lane of the wave solves the same system, so whether a transposition is needed at all is
+         * wave-uniform: the selects are skipped when the pivot already sits in row or column kk
+         * (always so for the first pivot of a moment matrix, whose largest entry is the sum of the
+         * weights). */
+        if (__builtin_amdgcn_readfirstlane(br) != kk) {
 #pragma unroll
-        for (int r = kk + 1; r < N; ++r) {
-            const bool sw = r == br;
+            for (int r = kk + 1; r < N; ++r) {
+                const bool sw = r == br;
 #pragma unroll
-            for (int c = 0; c < N; ++c) {
-                const double a = lu[kk][c], b = lu[r][c];
-                lu[kk][c] = sw ? b : a;
-                lu[r][c] = sw ? a : b;
+                for (int c = 0; c < N; ++c) {
+                    const double a = lu[kk][c], b = lu[r][c];
+                    lu[kk][c] = sw ? b : a;
+                    lu[r][c] = sw ? a : b;
+                }
             }
         }
+        if (__builtin_amdgcn_readfirstlane(bc) != kk) {
 #pragma unroll
-        for (int c = kk + 1; c < N; ++c) {
-            const bool sw = c == bc;
+            for (int c = kk + 1; c < N; ++c) {
+                const bool sw = c == bc;
 #pragma unroll
-            for (int r = 0; r < N; ++r) {
-                const double a = lu[r][kk], b = lu[r][c];
-                lu[r][kk] = sw ? b : a;
-                lu[r][c] = sw ? a : b;
+                for (int r = 0; r < N; ++r) {
+                    const double a = lu[r][kk], b = lu[r][c];
+                    lu[r][kk] = sw ? b : a;
+                    lu[r][c] = sw ? a : b;
+                }
             }
         }
 #pragma unroll
