@@ -1788,6 +1788,27 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_reinit_rescan(DevParams P, const 
     if (lower == 0) queue[(size_t)(level % 3u) * qcap + atomicAdd(&ctl->cnt[level % 3u], 1u)] = i;
 }
 
+/* Several quotients by one denominator.  The compiler's double-precision division is
+ *   r0 = rcp(d); r1 = fma(r0, fma(-d, r0, 1), r0); r2 = fma(r1, fma(-d, r1, 1), r1);
+ *   q0 = n * r2; q = fma(fma(-d, q0, n), r2, q0)
+ * wrapped in scaling steps that do nothing unless an operand or the quotient is close to the ends
+ * of the exponent range (and a fix-up that only matters for zero, infinite or NaN operands: a zero
+ * numerator gives zero either way).  The first line depends on the denominator alone.  For callers
+ * that have ruled those cases out the quotient below has the bits of n / d
+ * (tools/allsum_check.hip compares the two over ten million random pairs). */
+struct shared_divisor {
+    double d, r;
+    __device__ __forceinline__ explicit shared_divisor(double den) : d(den) {
+        const double r0 = __builtin_amdgcn_rcp(den);
+        const double r1 = __builtin_fma(r0, __builtin_fma(-den, r0, 1.0), r0);
+        r = __builtin_fma(r1, __builtin_fma(-den, r1, 1.0), r1);
+    }
+    __device__ __forceinline__ double quotient(double n) const {
+        const double q0 = n * r;
+        return __builtin_fma(__builtin_fma(-d, q0, n), r, q0);
+    }
+};
+
 /* x + (x moved by W lanes to its partner block), W = 16 or 32, for a double */
 template <int W>
 __device__ __forceinline__ double rows_pair_sum(double x) {
@@ -1922,6 +1943,19 @@ __device__ __forceinline__ bool reinit_one(const DevParams& P, Rec* __restrict__
             }
     };
     auto add_A = [&](const double (&num)[N][N], double rhoj) {
+        /* ten quotients with one denominator: the reciprocal and its two refinement steps are formed
+         * once (shared_divisor); the same bits as ten divisions while no operand needs scaling, which
+         * the wave checks (densities between 1e-3 and 1e12, shares zero or above 1e-250 -- num[0][0]
+         * = W*m is the largest of a row's shares, the others carry one or two offsets on top) */
+        const bool plain_ok = rhoj > 1e-3 && rhoj < 1e12 && !(fabs(num[0][0]) < 1e-150 && num[0][0] != 0.0);
+        if (__ballot(!plain_ok) == 0ull) {
+            const shared_divisor d(rhoj);
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+#pragma unroll
+                for (int cc = r; cc < N; ++cc) A[r][cc] += d.quotient(num[r][cc]);
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll

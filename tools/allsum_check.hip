@@ -45,8 +45,36 @@ int check10() {
     printf("ten sums at once: %d mismatches\n", bad);
     return bad;
 }
+__global__ void kdiv(const double* num, const double* den, unsigned long long n, unsigned long long* bad) {
+    unsigned long long b = 0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const shared_divisor d(den[i]);
+        const double a = d.quotient(num[i]), w = num[i] / den[i];
+        if (__double_as_longlong(a) != __double_as_longlong(w)) ++b;
+    }
+    if (b) atomicAdd(bad, b);
+}
+int check_div() {
+    const unsigned long long n = 10000000ull;
+    double *hn = (double*)malloc(8 * n), *hd = (double*)malloc(8 * n), *dn, *dd;
+    unsigned long long *dbad, hbad = 0;
+    for (unsigned long long i = 0; i < n; ++i) {
+        /* numerators: zero, or 1e-250 .. 1e3 of either sign; denominators 1e-3 .. 1e12 */
+        const double en = -250.0 + 253.0 * (rand() / (double)RAND_MAX), ed = -3.0 + 15.0 * (rand() / (double)RAND_MAX);
+        hn[i] = (rand() % 50 == 0) ? 0.0 : ((rand() & 1) ? -1.0 : 1.0) * (1.0 + rand() / (double)RAND_MAX) * pow(10.0, en);
+        hd[i] = (1.0 + rand() / (double)RAND_MAX) * pow(10.0, ed);
+    }
+    hipMalloc(&dn, 8 * n); hipMalloc(&dd, 8 * n); hipMalloc(&dbad, 8);
+    hipMemcpy(dn, hn, 8 * n, hipMemcpyHostToDevice); hipMemcpy(dd, hd, 8 * n, hipMemcpyHostToDevice);
+    hipMemset(dbad, 0, 8);
+    hipLaunchKernelGGL(kdiv, dim3(1024), dim3(256), 0, 0, dn, dd, n, dbad);
+    hipMemcpy(&hbad, dbad, 8, hipMemcpyDeviceToHost);
+    printf("quotients by a shared reciprocal against the division: %llu of %llu differ\n", hbad, n);
+    return hbad != 0;
+}
 int main() {
     if (check10()) return 1;
+    if (check_div()) return 1;
     double h[64], ha[64], hb[64], *d, *da, *db;
     hipMalloc(&d, 512); hipMalloc(&da, 512); hipMalloc(&db, 512);
     int bad = 0;
