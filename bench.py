@@ -180,7 +180,7 @@ def rooflines(n_launch, n_total, dev, pairs_per_particle):
         "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
         "traffic": None, "algorithmic_bytes_per_launch": b_alg, "kernel_ms": dev["pair_ms"],
         "launches": dev["pair_launches"], "algorithmic_bytes_per_particle_sweep": B_ALG_PAIR + B_ALG_UPDATE,
-        "limiter": "vector-instruction issue and the gather -> LDS transpose chain (not bytes): see fp64 and DESIGN.md",
+        "limiter": "vector-instruction issue and the gather -> LDS transpose chain (not bytes): see the fp64 figure beside it",
         "fp64": {"achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": ach_tf / FP64_PEAK_TFLOPS, "flop_per_pair": FLOP_PER_PAIR},
     }
