@@ -95,6 +95,7 @@ struct sph_ctx {
     const uint32_t* use_cnt = nullptr;
     uint32_t* need = nullptr;
     GridParams grid;
+    QLattice lattice; /* of the draw's 8-byte position entries, set at every rebuild */
     bool list_valid = false;
     bool lists_for_step = false; /* built by the stepping path (wall-wall pairs may be left out) */
     double skin_frac = 0.05, r_list2 = 0, disp_limit = 0;
@@ -306,11 +307,9 @@ void launch_hash(sph_ctx* c, const Rec* r, uint32_t m, const uint32_t* drop, uin
     else hipLaunchKernelGGL(k_hash<2>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, c->grid, drop, keys);
 }
 
-/* Where the draw's 16-byte entries and the particles' rebuild-time cells live: in the spare
- * record array (64 bytes per particle, free between a reorder and the next one), behind the
- * list build's 16-byte entries. */
-inline DPos* dpos_of(sph_ctx* c) { return (DPos*)((char*)c->rec_alt + (size_t)c->cap * 16); }
-inline uint32_t* cellc_of(sph_ctx* c) { return (uint32_t*)((char*)c->rec_alt + (size_t)c->cap * 32); }
+/* Where the draw's 8-byte entries live: in the spare record array (64 bytes per particle, free
+ * between a reorder and the next one), behind the list build's 16-byte entries. */
+inline uint2* qpos_of(sph_ctx* c) { return (uint2*)((char*)c->rec_alt + (size_t)c->cap * 16); }
 
 int ensure_step_lists(sph_ctx* c, bool* ok);
 
@@ -321,7 +320,7 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below, bool with_step_li
      * (in the spare record array, which nothing else uses between a reorder and the next one) */
     const uint32_t m = c->n + c->n_halo;
     hipLaunchKernelGGL(k_fill_pos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, wall_ids(c), m, c->grid, c->dim,
-                       c->dp.bound_parts, (Pos*)c->rec_alt, cellc_of(c));
+                       c->dp.bound_parts, (Pos*)c->rec_alt);
     const Pos* pos = (const Pos*)c->rec_alt;
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
@@ -783,8 +782,10 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     g.nrun = (uint32_t)g.n[run] * c->run_fine;
     g.invf = g.inv[run] * (double)c->run_fine;
     c->grid = g;
-    /* the draw refers to a particle's cell through a packed word */
-    if (g.n[0] > CELLC_MAX_X || g.n[1] > CELLC_MAX_YZ || g.n[2] > CELLC_MAX_YZ) c->two_level = false;
+    /* the lattice of the draw's 8-byte entries, whose 32-bit byte offsets bound the array's size */
+    for (int d = 0; d < 3; ++d) c->lattice.org[d] = d < dim ? g.lo[d] : 0.0;
+    c->lattice.invq = DRAW_LATTICE_PER_RLIST / r_list;
+    if (c->cap >= (1u << 29)) c->two_level = false;
 
     /* sort the owned particles by cell */
     launch_hash(c, c->rec[src], m_sort, drop, c->keys);
@@ -994,16 +995,18 @@ int draw_step_lists(sph_ctx* c, const Rec* r) {
         ev = &c->dr_pool[c->dr_used++];
         HIPCHK(hipEventRecord(ev->a, c->stream));
     }
-    hipLaunchKernelGGL(k_fill_dpos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, cellc_of(c), m, c->grid, c->dim, dpos_of(c));
-    const double edge = 1.0 / c->grid.inv[0];
-    const float r2f = (float)(c->r_in2 * (1.0 + list_float_margin(edge, std::sqrt(c->r_list2))));
+    const QLattice& L = c->lattice;
+    hipLaunchKernelGGL(k_fill_qpos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, L, c->dim, qpos_of(c));
+    /* radius in lattice spacings, widened by the two spacings the rounding can cost */
+    const double rq = std::sqrt(c->r_in2) * L.invq + 2.0;
+    const uint32_t r2q = (uint32_t)std::ceil(rq * rq);
     const dim3 g(pairblocks(c->n)), b(SPH_BLOCK); /* 64 particles per workgroup, a multiple of 8 workgroups */
     if (c->dim == 3)
-        hipLaunchKernelGGL(k_draw_lists<3>, g, b, 0, c->stream, dpos_of(c), c->n, c->nbr, c->cap_k, c->cnt, (float)edge, r2f,
-                           c->nbr_in, c->cnt_in, c->S);
+        hipLaunchKernelGGL(k_draw_lists<3>, g, b, 0, c->stream, qpos_of(c), c->n, c->nbr, c->cap_k, c->cnt, r2q, c->nbr_in,
+                           c->cnt_in, c->S);
     else
-        hipLaunchKernelGGL(k_draw_lists<2>, g, b, 0, c->stream, dpos_of(c), c->n, c->nbr, c->cap_k, c->cnt, (float)edge, r2f,
-                           c->nbr_in, c->cnt_in, c->S);
+        hipLaunchKernelGGL(k_draw_lists<2>, g, b, 0, c->stream, qpos_of(c), c->n, c->nbr, c->cap_k, c->cnt, r2q, c->nbr_in,
+                           c->cnt_in, c->S);
     HIPCHK(hipGetLastError());
     if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
     if (c->trace && (c->draws++ % 16) == 0) { /* how the drawn rows fill the pair kernel's waves */

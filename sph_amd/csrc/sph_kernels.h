@@ -446,18 +446,9 @@ __host__ __device__ inline double list_float_margin(double edge, double r_list) 
     return LIST_FLOAT_MARGIN * (stretch > 1.0 ? stretch : 1.0);
 }
 
-/* A particle's cell at the last rebuild, packed: x in bits 0-11, y in 12-21, z in 22-31. */
-#define CELLC_MAX_X 4096
-#define CELLC_MAX_YZ 1024
-__device__ __forceinline__ uint32_t pack_cell(int cx, int cy, int cz) {
-    return (uint32_t)cx | ((uint32_t)cy << 12) | ((uint32_t)cz << 22);
-}
-
-/* also records every particle's cell (cellc may be null), which k_fill_dpos refers to later;
- * `id` is the array the wall test reads (particles below bound_parts are wall particles) */
+/* `id` is the array the wall test reads (particles below bound_parts are wall particles) */
 __global__ __launch_bounds__(SPH_BLOCK) void k_fill_pos(const Rec* __restrict__ rec, const uint32_t* __restrict__ id, uint32_t m,
-                                                        GridParams g, int dim, uint32_t bound_parts, Pos* __restrict__ pos,
-                                                        uint32_t* __restrict__ cellc) {
+                                                        GridParams g, int dim, uint32_t bound_parts, Pos* __restrict__ pos) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= m) return;
     const double x = rec[i].xv[0][0], y = rec[i].xv[1][0], z = rec[i].xv[2][0];
@@ -470,7 +461,6 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_fill_pos(const Rec* __restrict__ 
     p.w = dim == 3 ? (float)((z - g.lo[2]) - (double)cz * (1.0 / g.inv[2])) : 0.0f;
     p.tag = (uint32_t)(dim == 3 ? cz : cy) | (id[i] < bound_parts ? POS_WALL : 0u);
     pos[i] = p;
-    if (cellc) cellc[i] = pack_cell(cx, cy, cz);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -481,79 +471,133 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_fill_pos(const Rec* __restrict__ 
 /* every rebuild, k_draw_lists copies out of every candidate row the entries within               */
 /* r_in = R*(1+margin), in the row's order; the pair kernel walks those.  Membership is still      */
 /* decided exactly by the pair kernel: the draw only has to keep every pair within r_in, so it      */
-/* works on 16-byte single-precision entries: the particle's place relative to the low corner of    */
-/* the cell it was in at the last rebuild (formed in double, rounded once) and that cell.          */
-struct __attribute__((aligned(16))) DPos {
-    float u, v, w;
-    uint32_t cell;
+/* works on 8-byte entries: the low 16 bits of the particle's coordinates on a lattice of spacing    */
+/* q = r_list / 8192 (x and y in one word, z in the other).  Two particles of a candidate pair are     */
+/* less than 2 r_list apart along any axis, far inside the +-4 r_list that a 16-bit difference spans,  */
+/* so the wrapped differences are the true lattice differences, whatever the size of the domain;       */
+/* rounding to the lattice moves a particle by at most q/2 along each axis, so the distance of two     */
+/* entries is off by less than two spacings, by which the draw radius is widened.  All in integers.    */
+#define DRAW_LATTICE_PER_RLIST 8192.0
+struct QLattice {
+    double org[3]; /* lattice origin (the low corner of the cell box: keeps the coordinates small) */
+    double invq;   /* 1 / spacing */
 };
-__global__ __launch_bounds__(SPH_BLOCK) void k_fill_dpos(const Rec* __restrict__ rec, const uint32_t* __restrict__ cellc,
-                                                         uint32_t m, GridParams g, int dim, DPos* __restrict__ dpos) {
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(SPH_BLOCK) void k_fill_qpos(const Rec* __restrict__ rec, uint32_t m, QLattice L, int dim,
+                                                         uint2* __restrict__ qpos) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= m) return;
-    const uint32_t cc = cellc[i];
-    const double edge = 1.0 / g.inv[0]; /* all axes share one edge */
-    DPos p;
-    p.u = (float)((rec[i].xv[0][0] - g.lo[0]) - (double)(cc & 4095u) * edge);
-    p.v = (float)((rec[i].xv[1][0] - g.lo[1]) - (double)((cc >> 12) & 1023u) * edge);
-    p.w = dim == 3 ? (float)((rec[i].xv[2][0] - g.lo[2]) - (double)(cc >> 22) * edge) : 0.0f;
-    p.cell = cc;
-    dpos[i] = p;
+    auto low16 = [&](double x, double org) -> uint32_t {
+        const double r = rint((x - org) * L.invq);
+        return (uint32_t)(r - 65536.0 * floor(r * (1.0 / 65536.0))) & 0xFFFFu; /* exact: r is an integer */
+    };
+    uint2 p;
+    p.x = low16(rec[i].xv[0][0], L.org[0]) | (low16(rec[i].xv[1][0], L.org[1]) << 16);
+    p.y = dim == 3 ? low16(rec[i].xv[2][0], L.org[2]) : 0u;
+    qpos[i] = p;
 }
 
-/* Four lanes per particle; the quad takes sixteen entries of the candidate row per step: one
- * 16-byte read per lane, then four rounds in which the quad's lanes take four CONSECUTIVE
- * entries (consecutive entries of a row are mostly consecutive particles: the four 16-byte
- * gathers of a quad then fall into one 64-byte segment, and the vector-memory pipe is paced by
- * the distinct segments an instruction touches).  Keepers are appended in the row's order. */
+/* Four lanes per particle.  The first version of this kernel (quad-wide exchange of the row
+ * entries, 16-byte single-precision positions, a ballot and a scattered 4-byte store per kept
+ * entry) took 2.9 ms at 12.7 M particles, and taking it apart showed the parts adding up instead of
+ * overlapping: 1.1 ms of arithmetic alone, 0.2 ms for the row reads, 0.8 ms for the gathers
+ * (whatever their size, their addresses or the number in flight), 0.8 ms for the stores.  So the
+ * work per entry is kept small: a lane reads 16 bytes of the candidate row and deals with those
+ * four entries itself (no exchange inside the quad); the distance test is two packed 16-bit
+ * subtractions, two integer dot products and a compare; the keep flags of sixteen entries are
+ * combined across the quad into one mask in the row's order, from which every lane counts the
+ * keepers in front of its own; and the keepers are collected in LDS and written out as whole
+ * 16-byte groups at the end (rows with more than DRAW_STAGE keepers write the rest straight to
+ * memory): 1.98 ms, 0.18 ms of it k_fill_qpos.  Slots of the last group past the count hold the
+ * particle's own index: the pair kernel fetches what a row names before it looks at the count. */
+#define DRAW_GROUPS 2        /* 16-entry groups of the row per step (1, 2: 1.98 ms at 12.7 M particles; 4: 2.27 ms) */
+#define DRAW_STAGE 64        /* keepers per particle collected in LDS */
+#define DRAW_STAGE_STRIDE 68 /* words per particle there: 16-byte aligned rows, 8 distinct bank offsets */
 template <int DIM>
-__global__ __launch_bounds__(SPH_BLOCK) void k_draw_lists(const DPos* __restrict__ dpos, uint32_t n,
+__global__ __launch_bounds__(SPH_BLOCK) void k_draw_lists(const uint2* __restrict__ qpos, uint32_t n,
                                                           const uint32_t* __restrict__ nbr, uint32_t stride,
-                                                          const uint32_t* __restrict__ cnt, float edge, float r2f,
+                                                          const uint32_t* __restrict__ cnt, uint32_t r2q,
                                                           uint32_t* __restrict__ nbr_out, uint32_t* __restrict__ cnt_out,
                                                           DevScalars* __restrict__ S) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[(SPH_BLOCK / 4) * DRAW_STAGE_STRIDE];
     /* the lists drawn here start their own travel bound */
     if (blockIdx.x == 0 && threadIdx.x == 0) S->disp_in = 0.0;
-    const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
+    const uint32_t q = threadIdx.x & 3u;
     const uint32_t i_raw = xcd_contiguous_block() * (SPH_BLOCK / 4) + (threadIdx.x >> 2);
     const bool active = i_raw < n;
     const uint32_t i = active ? i_raw : n - 1;
-    const DPos pi = dpos[i];
+    const uint2 pi = qpos[i];
     const uint32_t c = active ? cnt[i] : 0u;
-    const int cxi = (int)(pi.cell & 4095u), cyi = (int)((pi.cell >> 12) & 1023u), czi = (int)(pi.cell >> 22);
+    const s16x2_t xyi = __builtin_bit_cast(s16x2_t, pi.x), zi = __builtin_bit_cast(s16x2_t, pi.y);
     const uint32_t* const row = nbr + (size_t)i * stride;
     uint32_t* const out = nbr_out + (size_t)i * stride;
+    uint32_t* const mine = stage + (threadIdx.x >> 2) * DRAW_STAGE_STRIDE;
     const uint32_t last_group = stride - 4u;
-    const uint32_t below = (1u << q) - 1u;
+    /* the bits of a sixteen-entry mask in front of this lane's four entries */
+    const uint32_t front = (1u << (4u * q)) - 1u;
     uint32_t k = 0;
-    for (uint32_t e0 = 0; e0 < c; e0 += 16u) {
-        const uint32_t eg = e0 + 4u * q;
-        const u32x4_t v = *(const u32x4_t*)(row + (eg < last_group ? eg : last_group));
-        uint32_t j[4];
-        DPos pj[4];
-        /* round m: the group that lane m read, entry q of it to lane q */
-#define DRAW_PICK(M)                                                          \
-    {                                                                         \
-        const uint32_t a0 = (uint32_t)quad_perm_i<(M)*0x55>((int)v.x);        \
-        const uint32_t a1 = (uint32_t)quad_perm_i<(M)*0x55>((int)v.y);        \
-        const uint32_t a2 = (uint32_t)quad_perm_i<(M)*0x55>((int)v.z);        \
-        const uint32_t a3 = (uint32_t)quad_perm_i<(M)*0x55>((int)v.w);        \
-        j[M] = q == 0 ? a0 : (q == 1 ? a1 : (q == 2 ? a2 : a3));              \
-        pj[M] = dpos[e0 + 4u * (M) + q < c ? j[M] : i];                       \
-    }
-        DRAW_PICK(0) DRAW_PICK(1) DRAW_PICK(2) DRAW_PICK(3)
-#undef DRAW_PICK
+    for (uint32_t e0 = 0; e0 < c; e0 += 16u * DRAW_GROUPS) {
+        uint32_t j[DRAW_GROUPS][4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int cxj = (int)(pj[m].cell & 4095u), cyj = (int)((pj[m].cell >> 12) & 1023u), czj = (int)(pj[m].cell >> 22);
-            const float dx = (float)(cxj - cxi) * edge + (pj[m].u - pi.u);
-            const float dy = (float)(cyj - cyi) * edge + (pj[m].v - pi.v);
-            const float dz = DIM == 3 ? (float)(czj - czi) * edge + (pj[m].w - pi.w) : 0.0f;
-            const bool keep = e0 + 4u * m + q < c && dx * dx + dy * dy + dz * dz <= r2f;
-            const uint32_t bits = (uint32_t)(__ballot(keep) >> (lane & 60u)) & 0xFu;
-            if (keep) out[k + __popc(bits & below)] = j[m];
-            k += __popc(bits);
+        for (int g = 0; g < DRAW_GROUPS; ++g) {
+            const uint32_t eg = e0 + 16u * g + 4u * q;
+            const u32x4_t v = *(const u32x4_t*)(row + (eg < last_group ? eg : last_group));
+            j[g][0] = v.x; j[g][1] = v.y; j[g][2] = v.z; j[g][3] = v.w;
         }
+        /* entries past the count are stale or zero but always index the arrays (the lists are
+         * cleared when allocated): they are fetched like the others and dropped by the flags */
+        uint2 pj[DRAW_GROUPS][4];
+#pragma unroll
+        for (int g = 0; g < DRAW_GROUPS; ++g)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) /* a 32-bit byte offset from the array's base (the host checks the size) */
+                pj[g][m] = *(const uint2*)((const char*)qpos + (j[g][m] << 3));
+#pragma unroll
+        for (int g = 0; g < DRAW_GROUPS; ++g) {
+            /* how many of this lane's four entries lie below the count */
+            const int room = (int)c - (int)(e0 + 16u * g + 4u * q);
+            uint32_t nib = 0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                /* wrapped 16-bit differences; their squares add up to less than 2^32 */
+                const s16x2_t dxy = __builtin_bit_cast(s16x2_t, pj[g][m].x) - xyi;
+                int d2 = __builtin_amdgcn_sdot2(dxy, dxy, 0, false);
+                if (DIM == 3) {
+                    const s16x2_t dz = __builtin_bit_cast(s16x2_t, pj[g][m].y) - zi;
+                    d2 = __builtin_amdgcn_sdot2(dz, dz, d2, false);
+                }
+                const bool keep = (m < room) & ((uint32_t)d2 <= r2q);
+                nib |= keep ? 1u << m : 0u;
+            }
+            /* the quad's sixteen flags, in the row's order, in every lane */
+            uint32_t w = nib << (4u * q);
+            w |= (uint32_t)quad_perm_i<0xB1>((int)w); /* [1,0,3,2] */
+            w |= (uint32_t)quad_perm_i<0x4E>((int)w); /* [2,3,0,1] */
+            const uint32_t base = k + __popc(w & front);
+            k += __popc(w);
+            /* keepers to their slots, the others to a spare word behind the row's slots */
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const uint32_t at = base + __popc(nib & ((1u << m) - 1u));
+                mine[((nib >> m) & 1u) && at < DRAW_STAGE ? at : DRAW_STAGE + q] = j[g][m];
+            }
+            if (k > DRAW_STAGE) { /* a long row: what does not fit goes straight to memory */
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint32_t at = base + __popc(nib & ((1u << m) - 1u));
+                    if (((nib >> m) & 1u) && at >= DRAW_STAGE) out[at] = j[g][m];
+                }
+            }
+        }
+    }
+    /* the collected keepers: whole groups of four, the tail padded with the particle itself */
+    const uint32_t kk = k < DRAW_STAGE ? k : DRAW_STAGE;
+    for (uint32_t e = 4u * q; e < kk; e += 16u) {
+        u32x4_t t = *(const u32x4_t*)(mine + e);
+        if (e + 1u >= kk) t.y = i;
+        if (e + 2u >= kk) t.z = i;
+        if (e + 3u >= kk) t.w = i;
+        *(u32x4_t*)(out + e) = t;
     }
     if (active && q == 0) cnt_out[i] = k;
 }

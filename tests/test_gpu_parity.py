@@ -487,16 +487,18 @@ def test_working_lists_too_tight_fall_back_to_the_candidates():
     sim.close()
 
 
-def test_step_lists_change_nothing_but_roundings():
+@pytest.mark.parametrize("skin,inner", [(0.3, 0.01), (1.5, 1.0)], ids=["narrow", "rows_past_the_staging_area"])
+def test_step_lists_change_nothing_but_roundings(skin, inner):
     # rows of the step lists keep the candidates' order and only drop pairs outside the radius; the
     # launch that draws them is a different instantiation of the kernel (its compiler may fuse
     # multiply-adds differently), so fields agree to roundings, not bit for bit -- also with a wide
-    # skin and many rebuilds
+    # skin and many rebuilds.  With a draw radius of 2 R the rows of particles inside the fluid keep
+    # more entries than the draw collects in LDS, so the remainder takes its path straight to memory.
     spec = CASES["wcxsph3d_block"]
     _, pc = util.both_cases(spec)
     out = []
-    for inner in (-1.0, 0.01):
-        sim = capi.Sim.from_case(pc, skin_frac=0.3, inner_skin_frac=inner)
+    for inner_frac in (-1.0, inner):
+        sim = capi.Sim.from_case(pc, skin_frac=skin, inner_skin_frac=inner_frac)
         sim.forces(capi.STATE_N)
         sim.zero_boundary_forces(capi.STATE_N)
         sc = sim.step(40)
