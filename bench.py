@@ -180,7 +180,9 @@ def rooflines(n_launch, n_total, dev, pairs_per_particle):
         "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
         "traffic": None, "algorithmic_bytes_per_launch": b_alg, "kernel_ms": dev["pair_ms"],
         "launches": dev["pair_launches"], "algorithmic_bytes_per_particle_sweep": B_ALG_PAIR + B_ALG_UPDATE,
-        "limiter": "vector-instruction issue and the gather -> LDS transpose chain (not bytes): see the fp64 figure beside it",
+        "limiter": "the L1 gather rate, not bytes or flops: an instruction whose 64 lanes fetch 16 scattered 64-byte records "
+                   "passes a compute unit every 44-50 cycles whether the lines come from L1 or L2 (tools/vmem_probe.hip), "
+                   "and a wave of the launch issues about 25 of them (6.35 rounds of 4): about 1.5 ms of the launch",
         "fp64": {"achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": ach_tf / FP64_PEAK_TFLOPS, "flop_per_pair": FLOP_PER_PAIR},
     }
