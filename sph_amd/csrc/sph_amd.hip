@@ -95,7 +95,8 @@ struct sph_ctx {
     const uint32_t* use_cnt = nullptr;
     uint32_t* need = nullptr;
     GridParams grid;
-    QLattice lattice; /* of the draw's 8-byte position entries, set at every rebuild */
+    QLattice lattice; /* of the 8-byte position entries the list build and the draw test, set at every rebuild */
+    bool check_lists = false; /* SPH_CHECK_LISTS: verify the rows after every list build */
     bool list_valid = false;
     bool lists_for_step = false; /* built by the stepping path (wall-wall pairs may be left out) */
     double skin_frac = 0.05, r_list2 = 0, disp_limit = 0;
@@ -307,8 +308,9 @@ void launch_hash(sph_ctx* c, const Rec* r, uint32_t m, const uint32_t* drop, uin
     else hipLaunchKernelGGL(k_hash<2>, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, c->grid, drop, keys);
 }
 
-/* Where the draw's 8-byte entries live: in the spare record array (64 bytes per particle, free
- * between a reorder and the next one), behind the list build's 16-byte entries. */
+/* Where the 8-byte lattice entries live: in the spare record array (64 bytes per particle, free
+ * between a reorder and the next one), a quarter of the way in -- the list build reads up to
+ * fifteen entries past the last particle, which still lie inside that array. */
 inline uint2* qpos_of(sph_ctx* c) { return (uint2*)((char*)c->rec_alt + (size_t)c->cap * 16); }
 
 int ensure_step_lists(sph_ctx* c, bool* ok);
@@ -316,12 +318,16 @@ int ensure_step_lists(sph_ctx* c, bool* ok);
 /* with_step_lists: the build writes the step lists too (radius r_in2), on the same positions */
 int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below, bool with_step_lists) {
     const uint32_t* hb = c->n_halo ? c->hbeg : nullptr;
-    /* positions and wall ids of the owned and the neighbours' particles, packed for the build
-     * (in the spare record array, which nothing else uses between a reorder and the next one) */
+    /* lattice entries and wall marks of the owned and the neighbours' particles (in the spare
+     * record array, which nothing else uses between a reorder and the next one) */
     const uint32_t m = c->n + c->n_halo;
-    hipLaunchKernelGGL(k_fill_pos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, wall_ids(c), m, c->grid, c->dim,
-                       c->dp.bound_parts, (Pos*)c->rec_alt);
-    const Pos* pos = (const Pos*)c->rec_alt;
+    const QLattice& L = c->lattice;
+    hipLaunchKernelGGL(k_fill_qpos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, L, c->dim, wall_ids(c), c->dp.bound_parts,
+                       qpos_of(c));
+    /* radii in lattice spacings, widened by the two spacings the rounding can cost */
+    const double rlq = std::sqrt(c->r_list2) * L.invq + 2.0, rinq = std::sqrt(c->r_in2) * L.invq + 2.0;
+    const uint32_t rl2q = (uint32_t)std::ceil(rlq * rlq), rin2q = (uint32_t)std::ceil(rinq * rinq);
+    if (c->cap_k & 3u) return fail(c, SPH_ESTATE, "list rows must hold a multiple of four entries");
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
         if (with_step_lists) { /* as many rows again, of the same length */
@@ -331,18 +337,38 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below, bool with_step_li
         uint32_t* const tin = with_step_lists ? c->nbr_in : nullptr;
         uint32_t* const tcnt = with_step_lists ? c->cnt_in : nullptr;
         if (c->dim == 3)
-            hipLaunchKernelGGL(k_build_list<3>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, pos, c->n, c->grid, c->cbeg,
-                               c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, c->r_in2, tin, tcnt);
+            hipLaunchKernelGGL(k_build_list<3>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid,
+                               c->cbeg, c->r_list2, rl2q, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, rin2q,
+                               tin, tcnt);
         else
-            hipLaunchKernelGGL(k_build_list<2>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, pos, c->n, c->grid, c->cbeg,
-                               c->r_list2, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, c->r_in2, tin, tcnt);
+            hipLaunchKernelGGL(k_build_list<2>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid,
+                               c->cbeg, c->r_list2, rl2q, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, rin2q,
+                               tin, tcnt);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         const uint32_t need = *c->need_host;
-        if (need <= c->cap_k) return SPH_OK;
+        if (need <= c->cap_k) {
+            if (c->check_lists) { /* development check: every word of every row names a particle slot */
+                uint32_t* bad = (uint32_t*)c->tmp;
+                HIPCHK(hipMemsetAsync(bad, 0, sizeof(uint32_t), c->stream));
+                hipLaunchKernelGGL(k_check_lists, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, c->nbr, c->cap_k, c->cap_k, c->cnt,
+                                   c->n, c->cap, bad);
+                if (tin)
+                    hipLaunchKernelGGL(k_check_lists, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, tin, c->cap_k, c->cap_k, tcnt,
+                                       c->n, c->cap, bad);
+                uint32_t h = 0;
+                HIPCHK(hipMemcpyAsync(&h, bad, sizeof h, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (h) return fail(c, SPH_ESTATE, "list check: a row names a slot beyond the arrays or holds too many entries");
+            }
+            return SPH_OK;
+        }
         /* some particle has more candidates than the lists hold: grow and build again */
-        const uint32_t newcap = (need + need / 8 + 7u) & ~3u;
+        /* rows of whole 128-byte lines: a stride that is not a multiple of 64 bytes makes every
+         * 16-entry group of a row straddle two lines (measured: a third more HBM reads in the pair
+         * launch and in the draw, 6 % and 18 % more time) */
+        const uint32_t newcap = (need + need / 8 + 31u) & ~31u;
         CHK(dfree(c, &c->nbr));
         CHK(dalloc(c, &c->nbr, (size_t)newcap * c->own_cap));
         HIPCHK(hipMemsetAsync(c->nbr, 0, sizeof(uint32_t) * (size_t)newcap * c->own_cap, c->stream));
@@ -996,7 +1022,7 @@ int draw_step_lists(sph_ctx* c, const Rec* r) {
         HIPCHK(hipEventRecord(ev->a, c->stream));
     }
     const QLattice& L = c->lattice;
-    hipLaunchKernelGGL(k_fill_qpos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, L, c->dim, qpos_of(c));
+    hipLaunchKernelGGL(k_fill_qpos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, L, c->dim, nullptr, 0u, qpos_of(c));
     /* radius in lattice spacings, widened by the two spacings the rounding can cost */
     const double rq = std::sqrt(c->r_in2) * L.invq + 2.0;
     const uint32_t r2q = (uint32_t)std::ceil(rq * rq);
@@ -1349,6 +1375,7 @@ int sph_create(const sph_params* p, sph_ctx** out) {
         c->inner_mode = -1;
     }
     if (const char* e = getenv("SPH_TRACE")) c->trace = atoi(e) != 0;
+    if (const char* e = getenv("SPH_CHECK_LISTS")) c->check_lists = atoi(e) != 0;
     if (const char* e = getenv("SPH_TWO_LEVEL_MIN_SKIN")) c->two_level_min_skin = atof(e);
     if (const char* e = getenv("SPH_SKIN_K2")) c->skin_k2 = atof(e);
     c->brick_log2 = c->dim == 3 ? 2u : 3u;
@@ -1429,7 +1456,7 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     CHK(dalloc(c, &c->perm_alt, n));
     c->cell_cap = std::max<size_t>(8 * n, (size_t)1 << 20);
     CHK(dalloc(c, &c->cbeg, c->cell_cap));
-    c->cap_k = p->max_neighbours > 0 ? (uint32_t)p->max_neighbours : (c->dim == 3 ? 96u : 40u);
+    c->cap_k = p->max_neighbours > 0 ? (uint32_t)p->max_neighbours : (c->dim == 3 ? 96u : 48u); /* defaults: whole 64-byte groups */
     c->cap_k = (c->cap_k + 3u) & ~3u;
     CHK(dalloc(c, &c->nbr, (size_t)c->cap_k * c->own_cap));
     /* the pair kernel fetches whole groups of a row: every entry, used or not, must index the arrays */

@@ -422,47 +422,6 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_walls_at_rest(WallRestArgs a, uin
 /* nbr[i*stride + k], so the rounds of the pair loop walk along cache lines they have already  */
 /* touched (stride is a multiple of 4: every 16-byte group is aligned).                        */
 
-/* What the list build reads of a candidate: 16 bytes, its position inside its cell as floats
- * (distance from the cell's low corner, formed in double and rounded once) and its wall index,
- * instead of three pieces of a 64-byte record and a word of the index array -- four consecutive
- * candidates are 64 contiguous bytes (the vector-memory pipe is paced by the distinct segments
- * an instruction touches), and the test is single-precision arithmetic.
- *
- * The lists only have to CONTAIN every pair within the list radius; the pair kernel decides
- * membership exactly.  With both ends inside their cells (|u| <= edge) the float distance of a
- * pair of particles one cell apart is off by less than 1e-6 of the cell edge per component
- * (two roundings to float of values <= edge, the float edge, two subtractions of values
- * <= 2 edges), its square by less than 3e-6 of edge^2; the build keeps d^2 <= (1 + 4e-5) rl^2. */
-struct __attribute__((aligned(16))) Pos {
-    float u, v, w;
-    uint32_t tag; /* bit 31: wall particle; below: the particle's cell along the run axis */
-};
-#define POS_WALL 0x80000000u
-#define LIST_FLOAT_MARGIN 4e-5
-/* The bound above is for cells of the list radius.  When a stray particle has blown the box up
- * the cells are stretched, and the float error grows with the edge: the margin follows it. */
-__host__ __device__ inline double list_float_margin(double edge, double r_list) {
-    const double stretch = edge / r_list;
-    return LIST_FLOAT_MARGIN * (stretch > 1.0 ? stretch : 1.0);
-}
-
-/* `id` is the array the wall test reads (particles below bound_parts are wall particles) */
-__global__ __launch_bounds__(SPH_BLOCK) void k_fill_pos(const Rec* __restrict__ rec, const uint32_t* __restrict__ id, uint32_t m,
-                                                        GridParams g, int dim, uint32_t bound_parts, Pos* __restrict__ pos) {
-    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
-    if (i >= m) return;
-    const double x = rec[i].xv[0][0], y = rec[i].xv[1][0], z = rec[i].xv[2][0];
-    const int cx = cell_coord(x, g.lo[0], g.inv[0], g.n[0]);
-    const int cy = cell_coord(y, g.lo[1], g.inv[1], g.n[1]);
-    const int cz = dim == 3 ? cell_coord(z, g.lo[2], g.inv[2], g.n[2]) : 0;
-    Pos p;
-    p.u = (float)((x - g.lo[0]) - (double)cx * (1.0 / g.inv[0]));
-    p.v = (float)((y - g.lo[1]) - (double)cy * (1.0 / g.inv[1]));
-    p.w = dim == 3 ? (float)((z - g.lo[2]) - (double)cz * (1.0 / g.inv[2])) : 0.0f;
-    p.tag = (uint32_t)(dim == 3 ? cz : cy) | (id[i] < bound_parts ? POS_WALL : 0u);
-    pos[i] = p;
-}
-
 /* ------------------------------------------------------------------------------------------ */
 /* Step lists.  The candidate lists carry a generous skin so that they survive several steps;  */
 /* a sweep only needs the candidates within the search radius plus what the particles move     */
@@ -472,18 +431,25 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_fill_pos(const Rec* __restrict__ 
 /* r_in = R*(1+margin), in the row's order; the pair kernel walks those.  Membership is still      */
 /* decided exactly by the pair kernel: the draw only has to keep every pair within r_in, so it      */
 /* works on 8-byte entries: the low 16 bits of the particle's coordinates on a lattice of spacing    */
-/* q = r_list / 8192 (x and y in one word, z in the other).  Two particles of a candidate pair are     */
-/* less than 2 r_list apart along any axis, far inside the +-4 r_list that a 16-bit difference spans,  */
-/* so the wrapped differences are the true lattice differences, whatever the size of the domain;       */
-/* rounding to the lattice moves a particle by at most q/2 along each axis, so the distance of two     */
-/* entries is off by less than two spacings, by which the draw radius is widened.  All in integers.    */
+/* q = r_list / 8192 (x and y in one word, z in the low half of the other).  The two particles of a    */
+/* candidate pair are less than 2 r_list apart along any axis, far inside the +-4 r_list that a 16-bit  */
+/* difference spans, so the wrapped differences are the true lattice differences, whatever the size of  */
+/* the domain; rounding to the lattice moves a particle by at most q/2 along each axis, so the distance */
+/* of two entries is off by less than two spacings, by which the radius is widened.  All in integers.   */
+/* The list build tests its candidates on the same entries (there bit 31 of the second word marks a     */
+/* wall particle): it meets particles up to two cell edges away, whose wrapped differences are still    */
+/* exact while a cell is no wider than 2 r_list, and beyond that can only make a far particle look      */
+/* near -- a row then holds an entry too many, never one too few.                                       */
 #define DRAW_LATTICE_PER_RLIST 8192.0
+#define QPOS_WALL 0x80000000u
 struct QLattice {
     double org[3]; /* lattice origin (the low corner of the cell box: keeps the coordinates small) */
     double invq;   /* 1 / spacing */
 };
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
+/* id != nullptr: particles whose id is below bound_parts are marked as wall particles */
 __global__ __launch_bounds__(SPH_BLOCK) void k_fill_qpos(const Rec* __restrict__ rec, uint32_t m, QLattice L, int dim,
+                                                         const uint32_t* __restrict__ id, uint32_t bound_parts,
                                                          uint2* __restrict__ qpos) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= m) return;
@@ -494,6 +460,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_fill_qpos(const Rec* __restrict__
     uint2 p;
     p.x = low16(rec[i].xv[0][0], L.org[0]) | (low16(rec[i].xv[1][0], L.org[1]) << 16);
     p.y = dim == 3 ? low16(rec[i].xv[2][0], L.org[2]) : 0u;
+    if (id && id[i] < bound_parts) p.y |= QPOS_WALL;
     qpos[i] = p;
 }
 
@@ -606,39 +573,51 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_draw_lists(const uint2* __restric
  * quad reads ONE range of the cell table: the fine cells along the run axis that a sphere of
  * the list radius around the particle can reach in that column (none if the column itself is
  * out of reach), own particles and, in a slab run, the neighbours' particles.  It tests the
- * range eight candidates at a time (two per lane, both fetches in flight together) and appends
- * the keepers in ascending order, so a row lists its candidates column by column (x slowest),
- * own particles before halo particles, ascending along the run axis. */
+ * range sixteen candidates at a time on their 8-byte lattice entries (k_fill_qpos): a lane reads
+ * its four consecutive entries with two 16-byte loads (the range is entered at an even index, so
+ * the loads are aligned) and tests them with packed 16-bit subtractions and integer dot products;
+ * the flags of the sixteen are combined across the quad into one mask per list in the range's
+ * order, from which every lane counts the keepers in front of its own.  Keepers wait in a ring of
+ * 32 words per list and particle in LDS and leave for memory sixteen at a time, as four aligned
+ * 16-byte stores of the quad; the last group of a row is padded with the particle's own index
+ * (the pair kernel fetches what a row names before it looks at the count).  A row lists its
+ * candidates column by column (x slowest), own particles before halo particles, ascending along
+ * the run axis.  (The version before this one -- 16-byte single-precision entries, two candidates
+ * per lane and trip, a ballot and a scattered 4-byte store per keeper and list -- took 5.3 ms at
+ * 12.7 M particles and 460 candidates tested per particle.) */
+#define BUILD_RING 32
+#define BUILD_STAGE_STRIDE (2 * BUILD_RING + 4) /* two rings and a spare word per lane */
+typedef uint32_t u32x4_t_a16 __attribute__((ext_vector_type(4), aligned(16)));
 template <int DIM>
-__global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict__ rec, const Pos* __restrict__ pos, uint32_t n,
+__global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict__ rec, const uint2* __restrict__ qpos, uint32_t n,
                                                           GridParams g,
-                                                          const uint32_t* __restrict__ cstart, double rl2,
+                                                          const uint32_t* __restrict__ cstart, double rl2, uint32_t rl2q,
                                                           uint32_t* __restrict__ nbr, uint32_t stride, uint32_t cap,
                                                           uint32_t* __restrict__ cnt, uint32_t* __restrict__ need,
                                                           int prune_walls, const uint32_t* __restrict__ hstart,
-                                                          double rin2, uint32_t* __restrict__ nbr_in,
+                                                          uint32_t rin2q, uint32_t* __restrict__ nbr_in,
                                                           uint32_t* __restrict__ cnt_in) {
-    const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
+    __shared__ __attribute__((aligned(16))) uint32_t stage[(SPH_BLOCK / 4) * BUILD_STAGE_STRIDE];
+    const uint32_t q = threadIdx.x & 3u;
     const uint32_t i_raw = xcd_contiguous_block() * (SPH_BLOCK / 4) + (threadIdx.x >> 2);
     const bool active = i_raw < n;
     const uint32_t i = active ? i_raw : n - 1;
-    /* prune_walls: pairs of two wall particles are left out (see k_walls_at_rest) */
-    const Pos pi = pos[i];
-    const bool i_wall = prune_walls && (pi.tag & POS_WALL);
-    const int crun_i = (int)(pi.tag & ~POS_WALL);
-    const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
-    const double run_i = DIM == 3 ? zi : yi;
+    const uint2 pi = qpos[i];
+    /* prune_walls: pairs of two wall particles are left out (see k_walls_at_rest): or-ed into the
+     * squared distance, a wall candidate's mark puts it beyond any radius */
+    const uint32_t wall_mask = (prune_walls && (pi.y & QPOS_WALL)) ? QPOS_WALL : 0u;
+    const s16x2_t xyi = __builtin_bit_cast(s16x2_t, pi.x), zi = __builtin_bit_cast(s16x2_t, pi.y);
+    const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi_d = DIM == 3 ? rec[i].xv[2][0] : 0.0;
+    const double run_i = DIM == 3 ? zi_d : yi;
     const double edge_d = 1.0 / g.inv[0]; /* all axes share one edge */
-    const float edge = (float)edge_d;
-    const double margin = list_float_margin(edge_d, sqrt(rl2));
-    const float rl2f = (float)(rl2 * (1.0 + margin));
     const int cx = cell_coord(xi, g.lo[0], g.inv[0], g.n[0]);
     const int cy = DIM == 3 ? cell_coord(yi, g.lo[1], g.inv[1], g.n[1]) : 0;
     uint32_t* const row = nbr + (size_t)i * stride;
-    /* nbr_in != nullptr: the step lists (the candidates within the smaller radius rin2, same
-     * order) are written as well, which saves the draw that would follow the rebuild */
-    uint32_t* const row_in = nbr_in ? nbr_in + (size_t)i * stride : nullptr;
-    const float rin2f = (float)(rin2 * (1.0 + margin));
+    /* nbr_in != nullptr: the step lists (the candidates within the smaller radius, same order)
+     * are written as well, which saves the draw that would follow the rebuild */
+    const bool two = nbr_in != nullptr;
+    uint32_t* const row_in = two ? nbr_in + (size_t)i * stride : nullptr;
+    uint32_t* const mine = stage + (threadIdx.x >> 2) * BUILD_STAGE_STRIDE;
     /* The particle's place inside its cell, in cell edges: the gap to a column on the low side
      * is fx, on the high side 1 - fx (never negative).  What a column can hold within reach lies
      * within sqrt(rl^2 - gap^2) of the particle along the run axis; the bound carries a margin
@@ -646,43 +625,78 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
     const double fx = fmin(fmax((xi - g.lo[0]) * g.inv[0] - (double)cx, 0.0), 1.0);
     const double fy = DIM == 3 ? fmin(fmax((yi - g.lo[1]) * g.inv[1] - (double)cy, 0.0), 1.0) : 0.0;
     const double reach2 = rl2 * g.inv[0] * g.inv[0] * (1.0 + 1e-6);
-    const uint32_t below = (1u << q) - 1u;
-    uint32_t k = 0, k_in = 0;
-    /* candidates [b, e) of a column whose cells are (dx, dy) away from the particle's */
-    auto walk = [&](uint32_t b, uint32_t e, float bx, float by) {
-        for (uint32_t j0 = b; j0 < e; j0 += 8) {
-            const uint32_t ja = j0 + q, jb = j0 + 4u + q;
-            const Pos pa = pos[ja < e ? ja : i], pb = pos[jb < e ? jb : i]; /* whole entries, no second fetch */
-            /* along the run axis the two particles may be several cells apart */
-            const float ra = (float)(crun_i - (int)(pa.tag & ~POS_WALL)) * edge, rb = (float)(crun_i - (int)(pb.tag & ~POS_WALL)) * edge;
-            float ax_, ay_, az_, cx_, cy_, cz_;
-            if (DIM == 3) {
-                ax_ = bx - pa.u; ay_ = by - pa.v; az_ = ra + (pi.w - pa.w);
-                cx_ = bx - pb.u; cy_ = by - pb.v; cz_ = rb + (pi.w - pb.w);
-            } else {
-                ax_ = bx - pa.u; ay_ = ra + (pi.v - pa.v); az_ = 0.0f;
-                cx_ = bx - pb.u; cy_ = rb + (pi.v - pb.v); cz_ = 0.0f;
+    /* the bits of a sixteen-candidate mask in front of this lane's four */
+    const uint32_t front = (1u << (4u * q)) - 1u;
+    uint32_t k = 0, k_in = 0; /* keepers so far */
+    uint32_t f = 0, f_in = 0; /* of them written to memory: multiples of 16 */
+    /* sixteen keepers [f, f+16) of a ring leave for their row */
+    auto flush16 = [&](const uint32_t* ring, uint32_t* dst_row, uint32_t done) {
+        const u32x4_t_a16 t = *(const u32x4_t_a16*)(ring + (done & (BUILD_RING - 1u)) + 4u * q);
+        if (done + 4u * q + 4u <= stride) *(u32x4_t_a16*)(dst_row + done + 4u * q) = t;
+    };
+    /* candidates [b, e) of one column; self_col: the range may hold the particle itself */
+    auto walk = [&](uint32_t b, uint32_t e, bool self_col) {
+        for (uint32_t j0 = b & ~1u; j0 < e; j0 += 16u) {
+            const uint32_t jl = j0 + 4u * q; /* this lane's first candidate */
+            /* in bounds of the array's allocation even past the last particle (see qpos_of) */
+            const u32x4_t_a16 A = *(const u32x4_t_a16*)(qpos + jl), B = *(const u32x4_t_a16*)(qpos + jl + 2u);
+            const uint32_t lo[4] = {A.x, A.z, B.x, B.z}, hi[4] = {A.y, A.w, B.y, B.w};
+            uint32_t nib = 0, nib_in = 0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                /* wrapped 16-bit differences; their squares add up to less than 2^31 */
+                const s16x2_t dxy = __builtin_bit_cast(s16x2_t, lo[m]) - xyi;
+                uint32_t d2 = (uint32_t)__builtin_amdgcn_sdot2(dxy, dxy, 0, false);
+                if (DIM == 3) {
+                    const uint32_t dzw = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2_t, hi[m]) - zi) & 0xFFFFu;
+                    const s16x2_t dz = __builtin_bit_cast(s16x2_t, dzw);
+                    d2 = (uint32_t)__builtin_amdgcn_sdot2(dz, dz, (int)d2, false);
+                }
+                d2 |= hi[m] & wall_mask;
+                nib |= d2 <= rl2q ? 1u << m : 0u;
+                nib_in |= d2 <= rin2q ? 1u << m : 0u;
             }
-            const float d2a = ax_ * ax_ + ay_ * ay_ + az_ * az_;
-            const float d2b = cx_ * cx_ + cy_ * cy_ + cz_ * cz_;
-            const bool keepa = active & (ja < e) & (ja != i) & (d2a <= rl2f) & !(i_wall & ((pa.tag & POS_WALL) != 0u));
-            const bool keepb = active & (jb < e) & (jb != i) & (d2b <= rl2f) & !(i_wall & ((pb.tag & POS_WALL) != 0u));
-            const uint32_t bitsa = (uint32_t)(__ballot(keepa) >> (lane & 60u)) & 0xFu;
-            const uint32_t bitsb = (uint32_t)(__ballot(keepb) >> (lane & 60u)) & 0xFu;
-            const uint32_t ata = k + __popc(bitsa & below);
-            const uint32_t atb = k + __popc(bitsa) + __popc(bitsb & below);
-            if (keepa && ata < cap) row[ata] = ja;
-            if (keepb && atb < cap) row[atb] = jb;
-            k += __popc(bitsa) + __popc(bitsb);
-            if (row_in) {
-                const bool ina = keepa & (d2a <= rin2f), inb = keepb & (d2b <= rin2f);
-                const uint32_t ia = (uint32_t)(__ballot(ina) >> (lane & 60u)) & 0xFu;
-                const uint32_t ib = (uint32_t)(__ballot(inb) >> (lane & 60u)) & 0xFu;
-                const uint32_t pa_ = k_in + __popc(ia & below);
-                const uint32_t pb_ = k_in + __popc(ia) + __popc(ib & below);
-                if (ina && pa_ < cap) row_in[pa_] = ja;
-                if (inb && pb_ < cap) row_in[pb_] = jb;
-                k_in += __popc(ia) + __popc(ib);
+            /* candidates in front of the range (an odd b), behind it, and the particle itself */
+            const int room = (int)e - (int)jl;
+            uint32_t ok = room >= 4 ? 0xFu : (room > 0 ? (1u << room) - 1u : 0u);
+            if (jl < b) ok &= ~1u;
+            if (self_col) {
+                const uint32_t s = i - jl;
+                if (s < 4u) ok &= ~(1u << s);
+            }
+            if (!active) ok = 0;
+            nib &= ok;
+            nib_in &= nib;
+            /* the quad's flags in the range's order, both lists in one word, in every lane */
+            uint32_t w = (nib | (nib_in << 16)) << (4u * q);
+            w |= (uint32_t)quad_perm_i<0xB1>((int)w); /* [1,0,3,2] */
+            w |= (uint32_t)quad_perm_i<0x4E>((int)w); /* [2,3,0,1] */
+            const uint32_t wl = w & 0xFFFFu, wi = w >> 16;
+            const uint32_t base = k + __popc(wl & front), base_in = k_in + __popc(wi & front);
+            k += __popc(wl);
+            k_in += __popc(wi);
+            /* keepers to their places in the rings, the others to this lane's spare word (what a
+             * full row cannot take passes through the ring too and is dropped where it would be
+             * stored: rows hold `stride` = `cap` entries) */
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const uint32_t at = base + __popc(nib & ((1u << m) - 1u));
+                mine[(nib >> m) & 1u ? (at & (BUILD_RING - 1u)) : 2 * BUILD_RING + q] = jl + (uint32_t)m;
+            }
+            if (k - f >= 16u) { /* at most 31 wait: the ring never wraps onto them */
+                flush16(mine, row, f);
+                f += 16u;
+            }
+            if (two) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint32_t at = base_in + __popc(nib_in & ((1u << m) - 1u));
+                    mine[(nib_in >> m) & 1u ? BUILD_RING + (at & (BUILD_RING - 1u)) : 2 * BUILD_RING + q] = jl + (uint32_t)m;
+                }
+                if (k_in - f_in >= 16u) {
+                    flush16(mine + BUILD_RING, row_in, f_in);
+                    f_in += 16u;
+                }
             }
         }
     };
@@ -703,29 +717,51 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
         const uint32_t fb = (uint32_t)cell_coord(run_i + hw, g.lo[DIM - 1], g.invf, (int)g.nrun);
         const uint32_t base = take ? column_index<DIM>(g, ax, ay) * g.nrun : 0u; /* column 0 always exists */
         const uint32_t b0 = cstart[base + fa], e0 = cstart[base + fb + 1u];
-        cb[t] = take ? b0 : 0xFFFFFFFFu;
+        cb[t] = take ? b0 : 0xFFFFFFFEu;
         ce[t] = take ? e0 : 0u;
         if (hstart) {
             const uint32_t b1 = hstart[base + fa], e1 = hstart[base + fb + 1u];
-            qb[t] = take ? b1 : 0xFFFFFFFFu;
+            qb[t] = take ? b1 : 0xFFFFFFFEu;
             qe[t] = take ? e1 : 0u;
         }
     }
 #pragma unroll
     for (int t = 0; t < NCOL; ++t) {
-        const int dx = DIM == 3 ? t / 3 - 1 : t - 1, dy = DIM == 3 ? t % 3 - 1 : 0;
-        /* x_i - x_j = (u_i - dx*edge) - u_j for a candidate dx cells away */
-        const float bx = pi.u - (float)dx * edge;
-        const float by = pi.v - (float)dy * edge;
         /* own particles of the range, then (slab runs) the neighbours' particles in it */
-        walk(cb[t], ce[t], bx, by);
-        if (hstart) walk(qb[t], qe[t], bx, by);
+        walk(cb[t], ce[t], t == NCOL / 2);
+        if (hstart) walk(qb[t], qe[t], false);
     }
+    /* what still waits in the rings: a last group each, padded with the particle itself */
+    auto finish = [&](const uint32_t* ring, uint32_t* dst_row, uint32_t done, uint32_t total) {
+        const uint32_t e = done + 4u * q;
+        if (e < total && e + 4u <= stride) {
+            u32x4_t_a16 t = *(const u32x4_t_a16*)(ring + (done & (BUILD_RING - 1u)) + 4u * q);
+            if (e + 1u >= total) t.y = i;
+            if (e + 2u >= total) t.z = i;
+            if (e + 3u >= total) t.w = i;
+            *(u32x4_t_a16*)(dst_row + e) = t;
+        }
+    };
+    const uint32_t kc = k < cap ? k : cap, kc_in = k_in < cap ? k_in : cap;
+    if (f < kc) finish(mine, row, f, kc);
+    if (two && f_in < kc_in) finish(mine + BUILD_RING, row_in, f_in, kc_in);
     if (active && q == 0) {
-        cnt[i] = k < cap ? k : cap;
+        cnt[i] = kc;
         if (k > cap) atomicMax(need, k);
-        if (row_in) cnt_in[i] = k_in < cap ? k_in : cap;
+        if (two) cnt_in[i] = kc_in;
     }
+}
+
+/* Development check (SPH_CHECK_LISTS): every word of every row must name a particle slot, and no
+ * count may exceed the rows' capacity; bad[0] counts the offenders. */
+__global__ __launch_bounds__(SPH_BLOCK) void k_check_lists(const uint32_t* __restrict__ nbr, uint32_t stride, uint32_t cap,
+                                                           const uint32_t* __restrict__ cnt, uint32_t n, uint32_t slots,
+                                                           uint32_t* __restrict__ bad) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t wrong = cnt[i] > cap ? 1u : 0u;
+    for (uint32_t e = 0; e < stride; ++e) wrong += nbr[(size_t)i * stride + e] >= slots ? 1u : 0u;
+    if (wrong) atomicAdd(bad, wrong);
 }
 
 /* Diagnostic (SPH_TRACE): how well the rows of one list fill the pair kernel's waves.  A wave
