@@ -1017,9 +1017,11 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
         const uint32_t a1 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).y);           \
         const uint32_t a2 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).z);           \
         const uint32_t a3 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).w);           \
-        /* entries past the count are stale or zero but always index the arrays (the lists are  \
-         * cleared when allocated); what is fetched for them is never used */                   \
-        load4(a0, a1, a2, a3);                                                                  \
+        /* a quad whose row ends before this round fetches nothing (a wave runs as many rounds  \
+         * as its longest row needs); within a row's last round the entries past the count are  \
+         * stale or zero but always index the arrays (the lists are cleared when allocated),   \
+         * and what is fetched for them is never used */                                        \
+        if (4u * (T) < c) load4(a0, a1, a2, a3);                                                \
     }
     auto exchange = [&]() -> Rec {
         /* the copies left a round ago; the vector-memory counter also covers them */

@@ -4,11 +4,13 @@
 // the figure printed is  time x CUs x clock / instructions, i.e. the CU-cycles that pass per
 // wave-instruction when all CUs issue them back to back.
 // Measured on MI355X: gather64 50, l1set64 44, gather8 73 CU-cycles per instruction (about one lane
-// per cycle whether the lines come from L1 or L2); far64 177; stream8 49 and stream16 99 (those two
-// run at the HBM rate, 6.4 TB/s).
+// per cycle whether the lines come from L1 or L2); half64 28, quarter64 22 (so about 16 cycles per
+// instruction and 2.1 per active quad); far64 177; stream8 49 and stream16 99 (those two run at the
+// HBM rate, 6.4 TB/s).
 //   gather64 : each quad reads one 64-byte record, 16 bytes per lane (the pair kernel's fetch),
 //              records near the wave's own place (hits in L2) or anywhere (misses)
 //   l1set64  : each quad reads one of 256 records that stay in L1 (16 distinct records per instruction)
+//   half64, quarter64 : gather64 with 8 and with 4 of the 16 quads of every wave active
 //   gather8  : each lane reads its own 8-byte entry near the wave's place (the draw's gather)
 //   stream8  : 64 lanes read 512 contiguous bytes (the pair kernel's state-n loads)
 //   stream16 : 64 lanes read 1024 contiguous bytes
@@ -39,7 +41,8 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
     return x;
 }
 
-// MODE 0 gather64 near, 1 gather64 far, 3 gather8 near, 4 stream8, 5 stream16, 6 l1set64
+// MODE 0 gather64 near, 1 gather64 far, 3 gather8 near, 4 stream8, 5 stream16, 6 l1set64,
+// 7 gather64 near with every other quad switched off, 8 with all quads but four switched off
 template <int MODE>
 __global__ __launch_bounds__(256) void probe(const char* __restrict__ buf, uint32_t nrec, uint32_t* __restrict__ sink) {
     __shared__ uint32_t hold[10240]; // 40 KB: four workgroups per CU, four waves per SIMD
@@ -54,7 +57,12 @@ __global__ __launch_bounds__(256) void probe(const char* __restrict__ buf, uint3
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const uint32_t t = (uint32_t)(r * 8 + m);
-            if (MODE == 0 || MODE == 1) {
+            if (MODE == 7 || MODE == 8) {
+                const uint32_t h = mix(quad * 64u + t);
+                const uint32_t rec = (quad + (h & 2047u)) % nrec;
+                got[m] = 0;
+                if (MODE == 7 ? ((lane >> 2) & 1u) != 0u : (lane >> 2) < 4u) got[m] = (*(const u32x4*)(buf + (size_t)rec * 64u + 16u * q)).x;
+            } else if (MODE == 0 || MODE == 1) {
                 const uint32_t h = mix(quad * 64u + t);
                 const uint32_t rec = MODE == 0 ? (quad + (h & 2047u)) % nrec : h % nrec; // in bounds by the modulus
                 got[m] = (*(const u32x4*)(buf + (size_t)rec * 64u + 16u * q)).x;
@@ -111,6 +119,8 @@ int main() {
     CHECK(hipMemset(buf, 1, (size_t)nrec * 64));
     CHECK(hipMemset(sink, 0, 64));
     run<0>("gather64", buf, 12700000u, sink, cus, mhz);
+    run<7>("half64", buf, 12700000u, sink, cus, mhz);
+    run<8>("quarter64", buf, 12700000u, sink, cus, mhz);
     run<1>("far64", buf, 12700000u, sink, cus, mhz);
     run<6>("l1set64", buf, 12700000u, sink, cus, mhz);
     run<3>("gather8", buf, 12700000u, sink, cus, mhz);
