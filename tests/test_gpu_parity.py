@@ -514,6 +514,22 @@ def test_step_lists_change_nothing_but_roundings(skin, inner):
         assert util.float_ulp_diff(x["rho"], y["rho"]).max() <= 1
 
 
+def test_every_row_names_particle_slots(monkeypatch):
+    # the pair kernel fetches what a row names before it looks at the row's count, so every word of
+    # every row -- entries, padding, leftovers of earlier builds -- must index the arrays; with
+    # SPH_CHECK_LISTS the library verifies that after each list build (rows grown twice on the way)
+    monkeypatch.setenv("SPH_CHECK_LISTS", "1")
+    spec = CASES["wcxsph3d_block"]
+    _, pc = util.both_cases(spec)
+    sim = capi.Sim.from_case(pc, skin_frac=0.3, max_neighbours=16)
+    sim.forces(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    sc = sim.step(60)
+    assert sc["step_redos"] == 0 and sc["hit_pairs"] > 0
+    sim.density_reinit()
+    sim.close()
+
+
 # ---- droplet / jet bodies (initialisers beyond the reference's box block) ------------------------
 
 @pytest.mark.parametrize("name", list(util.drop_cases()))

@@ -5,13 +5,14 @@
 // wave-instruction when all CUs issue them back to back.
 // Measured on MI355X: gather64 50, l1set64 44, gather8 73 CU-cycles per instruction (about one lane
 // per cycle whether the lines come from L1 or L2); half64 28, quarter64 22 (so about 16 cycles per
-// instruction and 2.1 per active quad); far64 177; stream8 49 and stream16 99 (those two run at the
+// instruction and 2.1 per active quad); gather8x4 46; far64 177; stream8 49 and stream16 99 (those two run at the
 // HBM rate, 6.4 TB/s).
 //   gather64 : each quad reads one 64-byte record, 16 bytes per lane (the pair kernel's fetch),
 //              records near the wave's own place (hits in L2) or anywhere (misses)
 //   l1set64  : each quad reads one of 256 records that stay in L1 (16 distinct records per instruction)
 //   half64, quarter64 : gather64 with 8 and with 4 of the 16 quads of every wave active
 //   gather8  : each lane reads its own 8-byte entry near the wave's place (the draw's gather)
+//   gather8x4: gather8 with the four lanes of a quad on four consecutive entries
 //   stream8  : 64 lanes read 512 contiguous bytes (the pair kernel's state-n loads)
 //   stream16 : 64 lanes read 1024 contiguous bytes
 // build: hipcc --offload-arch=gfx950 -O3 -o vmem_probe tools/vmem_probe.hip
@@ -42,7 +43,8 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
 }
 
 // MODE 0 gather64 near, 1 gather64 far, 3 gather8 near, 4 stream8, 5 stream16, 6 l1set64,
-// 7 gather64 near with every other quad switched off, 8 with all quads but four switched off
+// 7 gather64 near with every other quad switched off, 8 with all quads but four switched off,
+// 9 gather8 with the four lanes of a quad on four consecutive entries (32 contiguous bytes)
 template <int MODE>
 __global__ __launch_bounds__(256) void probe(const char* __restrict__ buf, uint32_t nrec, uint32_t* __restrict__ sink) {
     __shared__ uint32_t hold[10240]; // 40 KB: four workgroups per CU, four waves per SIMD
@@ -69,6 +71,10 @@ __global__ __launch_bounds__(256) void probe(const char* __restrict__ buf, uint3
             } else if (MODE == 6) {
                 const uint32_t rec = (mix(quad * 64u + t) + dep) & 255u; // a 16 KB set: stays in L1
                 got[m] = (*(const u32x4*)(buf + rec * 64u + 16u * q)).x;
+            } else if (MODE == 9) {
+                const uint32_t h = mix(quad * 64u + t);
+                const uint32_t ent = (quad * 8u + (h & 4095u)) % (nrec * 8u - 4u) + q; // + q stays inside nrec*8 entries
+                got[m] = (*(const u32x2*)(buf + (size_t)ent * 8u)).x;
             } else if (MODE == 3) {
                 const uint32_t h = mix((quad * 4u + q) * 64u + t);
                 const uint32_t ent = (quad * 8u + (h & 4095u)) % (nrec * 8u); // 8-byte entries: nrec*8 of them fit
@@ -124,6 +130,7 @@ int main() {
     run<1>("far64", buf, 12700000u, sink, cus, mhz);
     run<6>("l1set64", buf, 12700000u, sink, cus, mhz);
     run<3>("gather8", buf, 12700000u, sink, cus, mhz);
+    run<9>("gather8x4", buf, 12700000u, sink, cus, mhz);
     run<4>("stream8", buf, nrec, sink, cus, mhz);
     run<5>("stream16", buf, nrec, sink, cus, mhz);
     CHECK(hipFree(buf)); CHECK(hipFree(sink));
