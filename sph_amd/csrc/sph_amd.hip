@@ -90,7 +90,8 @@ struct sph_ctx {
     bool two_level = false;        /* decided at each rebuild */
     bool step_lists_valid = false; /* nbr_in serves the positions state n+1 holds now */
     double in_travel = 0;          /* running estimate of the travel between a step's second and last sweep */
-    double two_level_min_skin = 0.08, skin_k1 = 2.2, skin_k2 = 12.0;
+    double two_level_min_skin = 0.08, skin_k1 = 2.2, skin_k2 = 12.0, skin_max = 0.5;
+    bool skin_k2_auto = true; /* skin_k2 follows the memory left for the list rows (end of sph_create) */
     const uint32_t* use_nbr = nullptr; /* what the pair kernel walks in the sweep under way */
     const uint32_t* use_cnt = nullptr;
     uint32_t* need = nullptr;
@@ -709,7 +710,7 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
          * lists no sweep does (only the draw reads them, once per step), and a wider skin (k = 12) pays. */
         const double u = c->step_travel / Rs;
         const double s1 = std::min(0.5, std::max(0.03, std::max(std::sqrt(c->skin_k1 * u / dim), 5.0 * u)));
-        const double s2 = std::min(0.5, std::max(0.03, std::max(std::sqrt(c->skin_k2 * u / dim), 5.0 * u)));
+        const double s2 = std::min(c->skin_max, std::max(0.03, std::max(std::sqrt(c->skin_k2 * u / dim), 5.0 * u)));
         const bool two = c->inner_mode == 1 || (c->inner_mode == 0 && s2 >= c->two_level_min_skin);
         c->skin_frac = two ? s2 : s1;
     }
@@ -1377,7 +1378,9 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     if (const char* e = getenv("SPH_TRACE")) c->trace = atoi(e) != 0;
     if (const char* e = getenv("SPH_CHECK_LISTS")) c->check_lists = atoi(e) != 0;
     if (const char* e = getenv("SPH_TWO_LEVEL_MIN_SKIN")) c->two_level_min_skin = atof(e);
+    c->skin_k2_auto = getenv("SPH_SKIN_K2") == nullptr;
     if (const char* e = getenv("SPH_SKIN_K2")) c->skin_k2 = atof(e);
+    if (const char* e = getenv("SPH_SKIN_MAX")) c->skin_max = std::min(1.0, std::max(0.1, atof(e)));
     c->brick_log2 = c->dim == 3 ? 2u : 3u;
     if (const char* e = getenv("SPH_BRICK_LOG2")) c->brick_log2 = (uint32_t)std::min(5, std::max(0, atoi(e)));
     if (const char* e = getenv("SPH_RUN_FINE")) c->run_fine = (uint32_t)std::min(16, std::max(1, atoi(e)));
@@ -1514,6 +1517,14 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     c->S_host->dt_next = p->dt0;
     HIPCHK(hipMemcpyAsync(c->S, c->S_host, sizeof(DevScalars), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->skin_k2_auto) {
+        /* The wider skin (k = 24: a rebuild every seventh step instead of every fifth in the dam
+         * break, 3.5 % less time per step) needs rows of up to ~224 entries in both sets of
+         * lists, 1.8 KB per particle; a case that fills the GPU keeps the narrower one. */
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        c->skin_k2 = (double)c->own_cap * 1800.0 <= 0.5 * (double)free_b ? 24.0 : 12.0;
+    }
     return SPH_OK;
 }
 
