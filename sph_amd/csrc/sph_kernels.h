@@ -416,11 +416,13 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_walls_at_rest(WallRestArgs a, uin
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* candidate lists: every j != i with |xi-xj|^2 <= rl2 at build time (and the few the float  */
+/* candidate lists: every j != i with |xi-xj|^2 <= rl2 at build time (and the few the lattice */
 /* test lets in just beyond), in cell-range order                                            */
 /* then ascending j.  One row of `stride` entries per particle: entry k of particle i sits at  */
 /* nbr[i*stride + k], so the rounds of the pair loop walk along cache lines they have already  */
-/* touched (stride is a multiple of 4: every 16-byte group is aligned).                        */
+/* touched.  The stride is a multiple of 4 (every 16-byte group is aligned) and, whenever the  */
+/* library chooses it, of 32: rows then start on 128-byte lines, and no 64-byte group of a row */
+/* straddles two lines.                                                                        */
 
 /* ------------------------------------------------------------------------------------------ */
 /* Step lists.  The candidate lists carry a generous skin so that they survive several steps;  */
@@ -477,7 +479,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_fill_qpos(const Rec* __restrict__
  * 16-byte groups at the end (rows with more than DRAW_STAGE keepers write the rest straight to
  * memory): 1.98 ms, 0.18 ms of it k_fill_qpos.  Slots of the last group past the count hold the
  * particle's own index: the pair kernel fetches what a row names before it looks at the count. */
-#define DRAW_GROUPS 2        /* 16-entry groups of the row per step (1, 2: 1.98 ms at 12.7 M particles; 4: 2.27 ms) */
+#define DRAW_GROUPS 2        /* 16-entry groups of the row per step (12.7 M particles, 61 candidates each: 1.98 ms with 1 or 2,
+                              * 2.27 ms with 4; 77 candidates each: 2.03 ms with 1, 1.89 ms with 2) */
 #define DRAW_STAGE 64        /* keepers per particle collected in LDS */
 #define DRAW_STAGE_STRIDE 68 /* words per particle there: 16-byte aligned rows, 8 distinct bank offsets */
 template <int DIM>
