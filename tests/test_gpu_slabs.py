@@ -173,6 +173,33 @@ def test_planes_are_recut_towards_equal_load(tmp_path):
     assert after.max() / after.mean() < 1.25
 
 
+@pytest.mark.parametrize("body,nranks,transport", [("droplet", 4, "host"), ("jet", 3, "device")])
+def test_medium_size_droplet_and_jet_on_slabs_with_planes_recut(body, nranks, transport, tmp_path):
+    # the droplet case at a fifth of the spacing (~0.24 M particles, two thirds of them wall): the
+    # droplet starts within reach of the pool's surface, so density is non-uniform from the first
+    # sweep on; the box is cut evenly at first and re-cut every other step, so particles change
+    # owner in bulk at four ranks.  Against the CPU oracle on the whole domain.
+    # The jet (a slanted column reaching down to the pool) runs on three ranks over the
+    # device-buffer transport, the droplet on four over host staging.
+    if body == "droplet":
+        drop = dict(simtype=1, radius=0.31, centre=(0.95, 0.65, 0.72), v=(0.6, 0.0, -2.0))
+    else:
+        drop = dict(simtype=2, radius=0.21, centre=(0.75, 0.65, 0.92), height=1.0, v=(1.5, 0.0, -1.0))
+    spec = dict(program=2, npart=(80, 50, 15), pstep=0.02, box=(2.0, 1.4, 2.0), start=(0.1, 0.1, 0.1), drop=drop)
+    steps = 12
+    res = run_slabs(spec, nranks, tmp_path, steps=steps, even_planes=1, rebalance=2, transport=transport)
+    orc, f0, nb = oracle_run(spec, steps)
+    assert orc.npts > 200_000
+    check(res, orc, f0, nb, "0.24 M-particle %s on %d slabs, planes re-cut" % (body, nranks))
+    before, after = res["counts_before"].astype(float), res["moved"][:, 0].astype(float)
+    assert after.sum() == before.sum() == orc.npts
+    # the planes equalise a load in which a wall particle counts 0.4 of a fluid one, so the ranks
+    # holding the end walls end up with more particles than the others: what is checked is that
+    # particles did change owner in bulk and none was lost
+    assert res["moved"][:, 1].sum() > 1000 and res["moved"][:, 1].sum() == res["moved"][:, 2].sum()
+    assert not np.array_equal(before, after)
+
+
 @pytest.mark.parametrize("nranks", [2, 4])
 def test_medium_size_slabs_against_the_single_domain(nranks, tmp_path):
     # ~0.57 M particles: slabs wide enough to have an interior, so the boundary-first launches,
