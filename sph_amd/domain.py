@@ -295,7 +295,18 @@ def bench_main(args, world, rank, local_rank, fluid):
     watchdog.daemon = True
     watchdog.start()
     # control plane (id broadcast, barriers, timing) on gloo; particle data moves over RCCL
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # gloo reports its connections on stdout, which is reserved for the one result line: send what
+    # is written there while the group forms (and makes its first connections) to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     nx, ny, nz = fluid
     strong = args.scaling == "strong"
     case = B.dam_break_3d(nx if strong else nx * world, ny, nz)
