@@ -1000,6 +1000,9 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
      * issued once round t's records have been read out of the area (lgkmcnt) and are waited for
      * (vmcnt) a whole round of arithmetic later. */
     auto piece = [&](uint32_t j) -> const char* {
+#if defined(SPH_ABLATE) && (SPH_ABLATE & 1) /* timing experiment: every fetch aimed at the particle's own record */
+        j = i;
+#endif
         return !WIDE ? (const char*)rin + ((j << 6) | qoff) : (const char*)(rin + j) + 16 * q;
     };
     auto copy16 = [&](const char* src, char* dst_wave_base) {
@@ -1039,7 +1042,11 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
         const double Rx = rj.xv[0][0] - xi0, Ry = rj.xv[1][0] - xi1;
         const double Rz = DIM == 3 ? rj.xv[2][0] - xi2 : 0.0;
         const double d2 = dist2_exact(Rx, Ry, Rz);
+#if defined(SPH_ABLATE) && (SPH_ABLATE & 2) /* timing experiment: the arithmetic of every other round skipped */
+        const bool hit = valid && d2 < P.R2 && !(t & 1u);
+#else
         const bool hit = valid && d2 < P.R2;
+#endif
         hits += (uint32_t)__popcll(__ballot(hit));
         if (hit) {
             const double Vx = rj.xv[0][1] - vi0, Vy = rj.xv[1][1] - vi1;
