@@ -47,12 +47,22 @@ __device__ __forceinline__ uint32_t column_index(const GridParams& g, int cx, in
 }
 
 /* Workgroups are dealt round-robin to the eight XCDs, each with its own L2.  This maps
- * blockIdx.x (grid a multiple of 8) so that every XCD works through one contiguous eighth of
- * the cell-ordered particles: what a workgroup gathers is then what its neighbours on the same
- * L2 have just fetched.  (Placement only changes speed, never results.) */
+ * blockIdx.x (grid a multiple of 8) so that an XCD works through chunks of XCD_CHUNK consecutive
+ * blocks of the cell-ordered particles: what a workgroup gathers is then mostly what its
+ * neighbours on the same L2 have just fetched, and the chunks are dealt to the XCDs in turn, so
+ * that regions with little work per particle (dry floor, walls) are shared out evenly.
+ * (Placement only changes speed, never results.) */
+#ifndef XCD_CHUNK
+#define XCD_CHUNK 64u
+#endif
 __device__ __forceinline__ uint32_t xcd_contiguous_block() {
     const uint32_t per_xcd = gridDim.x >> 3;
-    return (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t x = blockIdx.x & 7u, l = blockIdx.x >> 3;
+    const uint32_t row = l / XCD_CHUNK, r = l % XCD_CHUNK;
+    /* rows of 8 chunks; the last row's chunks are shorter */
+    const uint32_t full = per_xcd / XCD_CHUNK;
+    const uint32_t width = row < full ? XCD_CHUNK : per_xcd - full * XCD_CHUNK;
+    return row * 8u * XCD_CHUNK + x * width + r;
 }
 
 __device__ __forceinline__ double wave_max(double v) {

@@ -5,8 +5,10 @@ set -u
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
+# PASSES="sq1 sq2 ta" limits the run to the named passes
 run() {
   name=$1; ctrs=$2; shift 2
+  if [ -n "${PASSES:-}" ] && ! [[ " $PASSES " == *" $name "* ]]; then return 0; fi
   timeout -s KILL 180 rocprofv3 --pmc $ctrs --kernel-include-regex "k_pair" --output-format csv -d "$out/$name" -- python bench.py --steps 2 --warmup 1 --no-cpu "$@" > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$out/$name.log"; return 1; }
   echo "pass $name ok"
 }
