@@ -139,16 +139,19 @@ int sph_zero_boundary_forces(sph_ctx* ctx, int32_t which_state);
 /* nsteps x Newmark_Beta(particles, particlesh, tree) (WCXSPH3D.cpp:251-303;
  * WCXSPH.cpp:245-298; WCSPH.cpp:245-296).  `out` may be NULL. */
 int sph_step(sph_ctx* ctx, int32_t nsteps, sph_scalars* out);
-/* sph_step for callers that cannot allocate device memory (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
- * kernels and same results as sph_step, but the pair kernel's per-workgroup partial results
- * and their fold live in a fixed array inside the library's code object (about 2.6 MB per GPU,
- * held until the process ends) instead of the context's buffers, and the call makes no
- * hipMalloc/hipFree: if a buffer would have to grow (the candidate lists overflow their rows)
- * it returns SPH_ENOMEM and the same step can be made through sph_step.  Single-domain
- * contexts of at most SPH_NOALLOC_MAX_PARTICLES particles; larger ones and slab contexts get
- * SPH_EINVAL.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
- * (two host threads, two contexts) race. */
+/* sph_step for callers that cannot allocate device memory (tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same kernels and same results as
+ * sph_step, but the pair kernel's per-workgroup partial results and their fold live in a fixed
+ * array inside the library's code object (about 2.6 MB per GPU, held until the process ends)
+ * instead of the context's buffers, and the call makes no hipMalloc/hipFree.  It is not a call
+ * for code under HIP graph capture: like sph_step it reads the step's scalars back and waits
+ * for the stream once per step (and a few times more when the lists are rebuilt).  If a
+ * buffer would have to grow (the candidate lists overflow their rows) it returns SPH_ENOMEM
+ * with state n untouched and the step in hand abandoned: the same step is then made through
+ * sph_step, which starts it again from its beginning.  Single-domain contexts of at most
+ * SPH_NOALLOC_MAX_PARTICLES particles; larger ones and slab contexts get SPH_EINVAL.  All calls
+ * on one GPU share that GPU's array: calls that overlap on one GPU (two host threads, two
+ * contexts) race. */
 #define SPH_NOALLOC_MAX_PARTICLES 4194304u
 int sph_step_noalloc(sph_ctx* ctx, int32_t nsteps, sph_scalars* out);
 /* Diagnostic: the first `nsweeps` sweeps (Forces + wall reset + update) of ONE

@@ -81,7 +81,11 @@ class Transport(C.Structure):
 
 
 class SphError(RuntimeError):
-    pass
+    """A call of the library returned a code other than SPH_OK; `code` holds it."""
+
+    def __init__(self, msg, code=None):
+        RuntimeError.__init__(self, msg)
+        self.code = code
 
 
 _lib = None
@@ -293,7 +297,7 @@ class Sim:
 
     def _chk(self, rc, what):
         if rc != OK:
-            raise SphError("%s: %s (code %d)" % (what, lib().sph_last_error(self._h).decode(), rc))
+            raise SphError("%s: %s (code %d)" % (what, lib().sph_last_error(self._h).decode(), rc), rc)
 
     def close(self):
         if getattr(self, "_h", None):

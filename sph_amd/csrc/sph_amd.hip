@@ -226,7 +226,10 @@ hipError_t scratch_of_current_device(int device, double** out) {
     } while (0)
 
 inline uint32_t nblk(uint32_t n) { return std::max(1u, (n + SPH_BLOCK - 1) / SPH_BLOCK); }
+/* workgroups of the list kernels (64 particles each) and of the pair kernel (PAIR_SPAN each) over
+ * `count` particles, a multiple of 8 */
 inline uint32_t pairblocks(uint32_t count) { return ((count + PAIR_PARTICLES - 1) / PAIR_PARTICLES + 7u) & ~7u; }
+inline uint32_t pairgrid(uint32_t count) { return count ? ((count + PAIR_SPAN - 1) / PAIR_SPAN + 7u) & ~7u : 0u; }
 
 int fail(sph_ctx* c, int code, const char* msg) {
     c->err = msg;
@@ -986,7 +989,7 @@ int launch_pair(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_out
                 uint32_t count, uint32_t part_base, uint32_t part_n) {
     if (count == 0) return SPH_OK;
     NState ns = n_state(c);
-    dim3 g(pairblocks(count)), b(PAIR_BLOCK);
+    dim3 g(pairgrid(count)), b(PAIR_BLOCK);
     /* record arrays of 4 GiB and more need 64-bit piece addresses */
     const bool wide = (uint64_t)c->cap * sizeof(Rec) >= (1ull << 32);
 #define LP(D, X, W)                                                                                                  \
@@ -1038,16 +1041,17 @@ int draw_step_lists(sph_ctx* c, const Rec* r) {
     if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
     if (c->trace && (c->draws++ % 16) == 0) { /* how the drawn rows fill the pair kernel's waves */
         unsigned long long* d = (unsigned long long*)c->tmp;
-        unsigned long long h[6];
+        unsigned long long h[8];
         HIPCHK(hipMemsetAsync(d, 0, sizeof h, c->stream));
         hipLaunchKernelGGL(k_rounds_stats, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, c->cnt_in, c->n, d);
-        hipLaunchKernelGGL(k_rounds_stats, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, c->cnt, c->n, d + 3);
+        hipLaunchKernelGGL(k_rounds_stats, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, c->cnt, c->n, d + 4);
         HIPCHK(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         const double waves = (c->n + 15) / 16;
-        fprintf(stderr, "[sph] draw: step lists %.2f entries/particle, %.2f rounds/wave run for %.2f needed per particle; "
+        fprintf(stderr, "[sph] draw: step lists %.2f entries/particle, %.2f rounds/wave run for %.2f needed per particle "
+                        "(%.2f with a workgroup's particles dealt to its waves by row length); "
                         "candidates %.2f entries/particle, %.2f rounds/wave\n",
-                (double)h[2] / c->n, h[0] / waves, (double)h[1] / c->n, (double)h[5] / c->n, h[3] / waves);
+                (double)h[2] / c->n, h[0] / waves, (double)h[1] / c->n, h[3] / waves, (double)h[6] / c->n, h[4] / waves);
     }
     return SPH_OK;
 }
@@ -1098,11 +1102,11 @@ int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, uint32_t* part_n_out
     const uint32_t n = c->n;
     OutState o = out_state(c, SPH_STATE_NP1);
     if (!c->dist) {
-        *part_n_out = pairblocks(n);
+        *part_n_out = pairgrid(n);
         return launch_sweep(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 0, n, 0, *part_n_out);
     }
     const uint32_t nL = c->iL_end, nR = n - c->iR_begin, nI = c->iR_begin - c->iL_end;
-    const uint32_t bL = nL ? pairblocks(nL) : 0, bR = nR ? pairblocks(nR) : 0, bI = nI ? pairblocks(nI) : 0;
+    const uint32_t bL = pairgrid(nL), bR = pairgrid(nR), bI = pairgrid(nI);
     const uint32_t part_n = bL + bR + bI;
     *part_n_out = part_n;
     CHK(launch_sweep(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 0, nL, 0, part_n));
@@ -1183,8 +1187,10 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
         if (two && !c->step_lists_valid) CHK(draw_step_lists(c, c->rec[cur]));
         for (int k = 0; k < nsweeps; ++k) {
             if (mode == 2 && k > 0) {
-                /* the start state is not needed again: let the sweep's input take its place */
-                c->b0 = cur;
+                /* the start state is not needed again: let the sweep's input take its place.  Not
+                 * in a call that may not allocate: there a rebuild whose rows overflow ends the
+                 * call, and the step is made again from its start through sph_step. */
+                if (!c->no_alloc) c->b0 = cur;
                 CHK(rebuild(c, cur, true));
             }
             int nxt = 0;
@@ -1706,7 +1712,7 @@ int sph_forces(sph_ctx* c, int32_t which) {
     /* lists built for state n's positions do not serve state n+1 */
     if (which == SPH_STATE_N) c->list_valid = false;
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1), 0, c->stream, c->S);
-    const uint32_t part_n = pairblocks(c->n);
+    const uint32_t part_n = pairgrid(c->n);
     CHK(launch_pair<false>(c, c->rec[src], nullptr, out_state(c, which), 1, 0, 0, c->n, 0, part_n));
     hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS, 1), dim3(SPH_BLOCK), 0, c->stream, c->part_use, part_n, 1, c->part2_use);
     hipLaunchKernelGGL(k_forces_finalize, dim3(1), dim3(1), 0, c->stream, c->S, c->part2_use);
@@ -2331,15 +2337,5 @@ int sph_use_rccl(sph_ctx* c, const void* unique_id_128) {
     return SPH_OK;
 }
 
-#ifdef SPH_PHASE_TIMING
-int sph_debug_read_phases(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    if (reset) {
-        unsigned long long z[8] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) != hipSuccess) return 1;
-    }
-    return 0;
-}
-#endif
 
 }  /* extern "C" */

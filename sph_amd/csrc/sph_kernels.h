@@ -109,6 +109,73 @@ __device__ __forceinline__ double quad_max(double v) {
     return v;
 }
 
+/* x and (x moved by W lanes to its partner block), W = 16 or 32, for a double: the row-swap
+ * instructions exchange the odd blocks of one copy with the even blocks of the other (vector ALU,
+ * no trip through the LDS crossbar), after which the two copies hold, lane by lane, the two
+ * numbers a shuffle by W would pair. */
+template <int W>
+__device__ __forceinline__ void rows_pair(double x, double& a, double& b) {
+    const uint32_t lo = (uint32_t)__double2loint(x), hi = (uint32_t)__double2hiint(x);
+    if (W == 16) {
+        const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        a = __hiloint2double((int)h[0], (int)l[0]);
+        b = __hiloint2double((int)h[1], (int)l[1]);
+    } else {
+        const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        a = __hiloint2double((int)h[0], (int)l[0]);
+        b = __hiloint2double((int)h[1], (int)l[1]);
+    }
+}
+template <int W>
+__device__ __forceinline__ double rows_pair_sum(double x) {
+    double a, b;
+    rows_pair<W>(x, a, b);
+    return a + b;
+}
+template <int W>
+__device__ __forceinline__ double rows_pair_max(double x) {
+    double a, b;
+    rows_pair<W>(x, a, b);
+    return fmax(a, b);
+}
+/* Wave-wide sum and maximum of a value that is the same in the four lanes of every quad, counted
+ * once per quad, in every lane, without the LDS crossbar: mirror images within eight and within
+ * sixteen lanes pair whole quads, the row swaps pair rows.  The order of additions is fixed. */
+__device__ __forceinline__ double quads_allsum(double v) {
+    v += quad_perm_d<0x141>(v); /* row_half_mirror */
+    v += quad_perm_d<0x140>(v); /* row_mirror */
+    v = rows_pair_sum<16>(v);
+    return rows_pair_sum<32>(v);
+}
+__device__ __forceinline__ double quads_allmax(double v) {
+    v = fmax(v, quad_perm_d<0x141>(v));
+    v = fmax(v, quad_perm_d<0x140>(v));
+    v = rows_pair_max<16>(v);
+    return rows_pair_max<32>(v);
+}
+/* The same for a value of its own in every lane: partners 1 and 2 apart in the quad first (after
+ * the quad steps every lane of a quad holds the quad's total, so the mirrors pair whole quads). */
+__device__ __forceinline__ double wave_allsum(double v) {
+    v += quad_perm_d<QP_XOR1>(v);
+    v += quad_perm_d<QP_XOR2>(v);
+    return quads_allsum(v);
+}
+__device__ __forceinline__ double wave_allmax(double v) {
+    v = fmax(v, quad_perm_d<QP_XOR1>(v));
+    v = fmax(v, quad_perm_d<QP_XOR2>(v));
+    return quads_allmax(v);
+}
+__device__ __forceinline__ uint32_t quads_allmax(uint32_t v) {
+    v = max(v, (uint32_t)quad_perm_i<0x141>((int)v));
+    v = max(v, (uint32_t)quad_perm_i<0x140>((int)v));
+    const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = max((uint32_t)a[0], (uint32_t)a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return max((uint32_t)b[0], (uint32_t)b[1]);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* bounding box of finite positions (per-block partials; the host finishes)                   */
 
@@ -779,7 +846,9 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_check_lists(const uint32_t* __res
 
 /* Diagnostic (SPH_TRACE): how well the rows of one list fill the pair kernel's waves.  A wave
  * takes 16 consecutive particles and runs max(ceil(count/4)) rounds.  out[0] += rounds summed
- * over the waves, out[1] += sum of ceil(count/4) over the particles, out[2] += entries. */
+ * over the waves, out[1] += sum of ceil(count/4) over the particles, out[2] += entries,
+ * out[3] += the rounds the waves would run if the 64 particles of a workgroup were dealt to its
+ * four waves in the order of their row lengths. */
 __global__ __launch_bounds__(SPH_BLOCK) void k_rounds_stats(const uint32_t* __restrict__ cnt, uint32_t n,
                                                             unsigned long long* __restrict__ out) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
@@ -790,6 +859,14 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_rounds_stats(const uint32_t* __re
     if ((threadIdx.x & 15u) == 0) atomicAdd(out, (unsigned long long)m);
     atomicAdd(out + 1, (unsigned long long)r);
     atomicAdd(out + 2, (unsigned long long)c);
+    /* rank of this particle's row length among the 64 of its wave (ties by lane) */
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t rank = 0;
+    for (int l = 0; l < 64; ++l) {
+        const uint32_t o = (uint32_t)__shfl((int)r, l);
+        rank += (o < r || (o == r && (uint32_t)l < lane)) ? 1u : 0u;
+    }
+    if ((rank & 15u) == 15u) atomicAdd(out + 3, (unsigned long long)r);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -860,12 +937,8 @@ __device__ __forceinline__ double fast_sqrt(double x) {
  * non-temporal hint, so that the L2 keeps what is reused: the neighbour records. */
 template <typename T>
 __device__ __forceinline__ T stream_load(const T* p) {
-#ifdef SPH_NT_LOADS
-    return __builtin_nontemporal_load(p);
-#else
-    return *p; /* measured: the hint on loads buys no time and costs 30 % more fetched bytes
-                  (a row's second half is fetched again) */
-#endif
+    return *p; /* measured: the non-temporal hint on loads buys no time and costs 30 % more
+                  fetched bytes (a row's second half is fetched again) */
 }
 template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
@@ -885,11 +958,13 @@ __device__ __forceinline__ float half_of(double pair, uint32_t which) {
     return __uint_as_float(which ? (uint32_t)(b >> 32) : (uint32_t)b);
 }
 
-#ifdef SPH_PHASE_TIMING /* development builds only: where a wave of the pair kernel spends its cycles */
-__device__ unsigned long long g_phase[8];
-#define PHASE_MARK(k) const unsigned long long tmark##k = __builtin_amdgcn_s_memtime();
-#else
-#define PHASE_MARK(k)
+/* Hooks for timing experiments (tools/pair_hooks.h, given to the compiler with -include by the
+ * tools that use them); they are empty in the library. */
+#ifndef PAIR_HOOK_FETCH
+#define PAIR_HOOK_FETCH(j, i)
+#endif
+#ifndef PAIR_HOOK_HIT
+#define PAIR_HOOK_HIT(hit, t)
 #endif
 
 #ifndef PAIR_WAVES
@@ -898,29 +973,39 @@ __device__ unsigned long long g_phase[8];
 #ifndef PAIR_BLOCK
 #define PAIR_BLOCK 256 /* threads per workgroup of the pair kernel */
 #endif
-#define PAIR_PARTICLES (PAIR_BLOCK / 4)
+#define PAIR_PARTICLES (SPH_BLOCK / 4)  /* particles per workgroup of the list kernels (four lanes each) */
+#define PAIR_GROUP 16                   /* particles a wave has in its rounds at a time: four lanes each */
+#define PAIR_GROUPS 4                   /* groups a wave works through: 64 particles, one per lane at the end */
+#define PAIR_WAVE_SPAN (PAIR_GROUP * PAIR_GROUPS)
+#define PAIR_SPAN ((PAIR_BLOCK / 64) * PAIR_WAVE_SPAN) /* particles per workgroup of the pair kernel */
 /* LDS transpose area: per wave four 1-KiB blocks (one per record of a quad's round); block r
  * is skewed by r*16 bytes so that the four lanes of a quad read four different 16-byte
  * bank groups */
 #define PAIR_LDS_BLOCK (1024 + 64)
 #define PAIR_LDS_WAVE (4 * PAIR_LDS_BLOCK)
+/* per wave: what the rounds leave for the finish, PAIR_KEEP doubles for each of its 64 particles */
+#define PAIR_KEEP 11
 
-/* Four lanes per particle of state n+1 (cell order), 16 particles per wave.
+/* A wave takes 64 consecutive particles of state n+1 (cell order).
  *
- *  Forces (WCXSPH3D.cpp:139-205).  Each lane of a quad walks every fourth entry of the
- *  particle's candidate list.  The four records a quad needs per round are fetched by the
- *  quad together -- lane q loads bytes 16q..16q+15 of each -- so one wave instruction
- *  touches 16 records of 64 contiguous bytes instead of 64 scattered 16-byte pieces (the
- *  vector memory pipe is paced by distinct segments per instruction).  The pieces are
- *  exchanged through a per-wave LDS area: copied there lane-linear straight from memory
- *  (global->LDS loads, no register stop), read back one whole record per lane.  The copies
- *  of round t+1 are in flight during the arithmetic of round t.  Pairs with
- *  dist2_exact < search_radius contribute momentum, continuity, XSPH and max(mu); the four
- *  partial sums of a quad are added at the end.
+ *  Forces (WCXSPH3D.cpp:139-205), four lanes per particle, 16 particles (a group) at a time, four
+ *  groups one after the other.  Each lane of a quad walks every fourth entry of the particle's
+ *  candidate list.  The four records a quad needs per round are fetched by the quad together --
+ *  lane q loads bytes 16q..16q+15 of each -- so one wave instruction touches 16 records of 64
+ *  contiguous bytes instead of 64 scattered 16-byte pieces (the vector memory pipe is paced by
+ *  distinct segments per instruction).  The pieces are exchanged through a per-wave LDS area:
+ *  copied there lane-linear straight from memory (global->LDS loads, no register stop), read
+ *  back one whole record per lane.  The copies of round t+1 are in flight during the arithmetic
+ *  of round t.  Pairs with dist2_exact < search_radius contribute momentum, continuity, XSPH and
+ *  max(mu); the four partial sums of a quad are added when the group's rounds are over and left
+ *  in LDS with the particle's position.
  *
- *  FUSED: the quad then performs the wall reset, the Newmark-beta update, the Tait pressure
- *  and the position-change sum for its particle (WCXSPH3D.cpp:260-285): lane d owns
- *  component d (and writes chunk d of the new record), lane 3 owns rho, p and Rrho.
+ *  The finish, one lane per particle (lane 4p+q takes particle 16q+p of the wave's 64): gravity,
+ *  the wall reset and, FUSED, the Newmark-beta update, the Tait pressure and the position-change
+ *  sum (WCXSPH3D.cpp:260-285).  In this form a wave instruction serves 64 particles instead of
+ *  16, every array of state n is read as one contiguous run with the array's base on the scalar
+ *  side (no per-lane choice of pointers), and the new records go out as whole kilobytes: they
+ *  are laid into the transpose area and stored lane-linear from there.
  */
 template <int DIM, bool XSPH, bool FUSED, bool WIDE>
 __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, const Rec* __restrict__ rin,
@@ -932,308 +1017,320 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
                                                     uint32_t first, uint32_t count, uint32_t part_base,
                                                     uint32_t part_n) {
     __shared__ __attribute__((aligned(16))) char stage[(PAIR_BLOCK / 64) * PAIR_LDS_WAVE];
-    PHASE_MARK(0)
+    __shared__ double keep[PAIR_BLOCK / 64][PAIR_KEEP][PAIR_WAVE_SPAN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = lane & 3;
-    /* Workgroups are dealt round-robin to the eight XCDs, each with its own L2.  Give every
-     * XCD one contiguous eighth of the cell-ordered particles, so that the records a
-     * workgroup gathers are the ones its neighbours on the same L2 have just fetched.
-     * (Placement only changes speed, never results.) */
+    const int q = lane & 3, p = lane >> 2;
+    /* Workgroups are dealt round-robin to the eight XCDs, each with its own L2; see
+     * xcd_contiguous_block.  (Placement only changes speed, never results.) */
     const uint32_t block = xcd_contiguous_block(); /* the grid is a multiple of 8 */
-    /* this launch covers particles [first, first+count) (a slab run launches its boundary
-     * layers and its interior separately) */
-    const uint32_t i_raw = first + block * PAIR_PARTICLES + (threadIdx.x >> 2);
-    const bool active = i_raw < first + count;
-    const uint32_t i = active ? i_raw : first + count - 1;
+    /* this launch covers particles [first, end) (a slab run launches its boundary layers and its
+     * interior separately); the wave's 64 start at wbase */
+    const uint32_t end = first + count;
+    const uint32_t wbase = first + block * PAIR_SPAN + (uint32_t)wave * PAIR_WAVE_SPAN;
     char* const wstage = stage + wave * PAIR_LDS_WAVE;
+    double (*const wkeep)[PAIR_WAVE_SPAN] = keep[wave];
 
-    const Rec ri = rin[i];
-    const double xi0 = ri.xv[0][0], xi1 = ri.xv[1][0], xi2 = ri.xv[2][0];
-    const double vi0 = ri.xv[0][1], vi1 = ri.xv[1][1], vi2 = ri.xv[2][1];
-    const double rho_i = (double)ri.rho;
     const double sqrtBgam = P.sqrtBgam;
-    const double c_i = sqrtBgam * fast_rsq(rho_i); /* sqrt(B*gam/rho), WCXSPH3D.cpp:172 */
     const double invH = P.invH;
     const double gconst = P.gconst;
-
-    /* The candidate row of particle i: entry e at nbr[i*cap + e].  Every fourth round each
-     * lane fetches 16 bytes of it: lane q holds the four candidates of round 4u+q. */
-    const uint32_t* const row = nbr + (size_t)i * stride;
-    /* unconditional and in bounds; entries past the count are replaced where they are used */
-    const uint32_t last_group = stride - 4u;
-    auto fetch_vec = [&](uint32_t u) -> uint4 {
-        const uint32_t e = u * 16u + (uint32_t)q * 4u;
-        const u32x4_t v = stream_load((const u32x4_t*)(row + (e < last_group ? e : last_group)));
-        return make_uint4(v.x, v.y, v.z, v.w);
-    };
-    /* the count and the head of the candidate row are requested together, and with them
-     * (FUSED) this lane's share of state n, which only the update after the pair loop reads:
-     * one trip to HBM for all of it instead of a second one after the loop */
-    const uint32_t c = active ? stream_load(cnt + i) : 0u;
-    const uint4 vhead = fetch_vec(0);
-    const uint4 vhead1 = fetch_vec(1);
-    const uint32_t my_id = id[i];
-    /* Every lane issues the same four 8-byte loads from addresses chosen with selects, and
-     * nothing looks at the values before the loop is over, so all of the above and these are
-     * in flight together.  (An array of pointers indexed by the lane's q would be read from
-     * the argument block in memory first: a second trip.)  Lane 3 takes the aligned pair of
-     * floats that holds its particle's Rrho, and the pair that holds its rho. */
-    double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
-    if (FUSED) {
-        const double* const pr = (const double*)ns.Rrho + (i >> 1);
-        const double* const pq = (const double*)ns.rho + (i >> 1);
-        const bool comp = q < DIM;
-        const double* const p0 = comp ? pick3(ns.f, q) + i : pr;
-        const double* const p1 = comp ? pick3(ns.v, q) + i : pq;
-        const double* const p3 = comp ? pick3(ns.x, q) + i : pr;
-        n0 = stream_load(p0);
-        n1 = stream_load(p1);
-        if (XSPH) n2 = stream_load(comp ? pick3(ns.V, q) + i : pq);
-        n3 = stream_load(p3);
-    }
-    /* rounds of four candidates; the trip count is made wave-uniform */
-    uint32_t rounds = (c + 3u) >> 2;
-#pragma unroll
-    for (int o = 32; o >= 4; o >>= 1) rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, o));
-    rounds = __builtin_amdgcn_readfirstlane(rounds);
-
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-    double Vs0 = 0.0, Vs1 = 0.0, Vs2 = 0.0;
-    double rr = 0.0, mumax = 0.0;
-
     /* While the record array is smaller than 4 GiB (!WIDE) a 32-bit byte offset from its base
      * addresses any piece: one shift-or per load instead of 64-bit arithmetic. */
     const uint32_t qoff = 16u * (uint32_t)q;
-    /* The pieces go from memory into the transpose area without a stop in registers: a 16-byte
-     * global->LDS copy, every lane naming its own source, the destination the wave-uniform base
-     * plus lane*16 -- the lane-linear image the transpose reads.  The copies of round t+1 are
-     * issued once round t's records have been read out of the area (lgkmcnt) and are waited for
-     * (vmcnt) a whole round of arithmetic later. */
-    auto piece = [&](uint32_t j) -> const char* {
-#if defined(SPH_ABLATE) && (SPH_ABLATE & 1) /* timing experiment: every fetch aimed at the particle's own record */
-        j = i;
-#endif
-        return !WIDE ? (const char*)rin + ((j << 6) | qoff) : (const char*)(rin + j) + 16 * q;
-    };
-    auto copy16 = [&](const char* src, char* dst_wave_base) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
-    };
-    auto load4 = [&](uint32_t j0, uint32_t j1, uint32_t j2, uint32_t j3) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the area has been read */
-        copy16(piece(j0), wstage);
-        copy16(piece(j1), wstage + 1 * PAIR_LDS_BLOCK + 16);
-        copy16(piece(j2), wstage + 2 * PAIR_LDS_BLOCK + 32);
-        copy16(piece(j3), wstage + 3 * PAIR_LDS_BLOCK + 48);
-    };
-    /* load round t, whose four candidates sit in lane (t & 3) of the quad */
-#define LOAD_FROM(VEC, R, T)                                                        \
-    {                                                                               \
-        const uint32_t a0 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).x);           \
-        const uint32_t a1 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).y);           \
-        const uint32_t a2 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).z);           \
-        const uint32_t a3 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).w);           \
-        /* a quad whose row ends before this round fetches nothing (a wave runs as many rounds  \
-         * as its longest row needs); within a row's last round the entries past the count are  \
-         * stale or zero but always index the arrays (the lists are cleared when allocated),   \
-         * and what is fetched for them is never used */                                        \
-        if (4u * (T) < c) load4(a0, a1, a2, a3);                                                \
+    const uint32_t last_group = stride - 4u;
+    uint32_t hits = 0; /* wave total, kept on the scalar side */
+    /* the time step of this sweep: read once, ahead of everything, and kept on the scalar side */
+    double dt = 0.0;
+    if (FUSED) {
+        const double v = S->dt;
+        dt = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
     }
-    auto exchange = [&]() -> Rec {
-        /* the copies left a round ago; the vector-memory counter also covers them */
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return *(const Rec*)(wstage + q * PAIR_LDS_BLOCK + q * 16 + (lane >> 2) * 64);
-    };
 
-    const int my_limit = (int)c - q; /* lane q holds entry 4t+q of round t: valid while 4t < c-q */
-    uint32_t hits = 0;               /* wave total, kept on the scalar side */
-    auto pair_term = [&](uint32_t t, const Rec& rj) {
-        const bool valid = (int)(t * 4u) < my_limit;
-        const double Rx = rj.xv[0][0] - xi0, Ry = rj.xv[1][0] - xi1;
-        const double Rz = DIM == 3 ? rj.xv[2][0] - xi2 : 0.0;
-        const double d2 = dist2_exact(Rx, Ry, Rz);
-#if defined(SPH_ABLATE) && (SPH_ABLATE & 2) /* timing experiment: the arithmetic of every other round skipped */
-        const bool hit = valid && d2 < P.R2 && !(t & 1u);
-#else
-        const bool hit = valid && d2 < P.R2;
-#endif
-        hits += (uint32_t)__popcll(__ballot(hit));
-        if (hit) {
-            const double Vx = rj.xv[0][1] - vi0, Vy = rj.xv[1][1] - vi1;
-            const double Vz = DIM == 3 ? rj.xv[2][1] - vi2 : 0.0;
-            const double r = fast_sqrt(d2);
-            const double qq = r * invH;
-            /* W2Kernel / W2GradK vanish for q >= 2 (WCXSPH3D.cpp:124,133): the clamp makes the
-             * factor (1 - q/2) an exact zero there */
-            const double t1 = fmax(1.0 - 0.5 * qq, 0.0);
-            const double t2 = t1 * t1;
-            const double gs = gconst * (t2 * t1);
-            const double Kern = XSPH ? (t2 * t2) * (2.0 * qq + 1.0) * P.correc : 0.0;
-            const double gx = Rx * gs, gy = Ry * gs, gz = Rz * gs;
-            const double rho_j = (double)rj.rho;
-            const double cbar = 0.5 * (c_i + sqrtBgam * fast_rsq(rho_j));
-            double vdotr = Vx * Rx + Vy * Ry;
-            if (DIM == 3) vdotr += Vz * Rz;
-            const double rhoij = 0.5 * (double)(ri.rho + rj.rho); /* float add, as the reference */
-            const double den = d2 + P.hvisc;
-            const double iw = fast_rcp(den * rhoij);
-            const double inv_rho = iw * den;
-            const double muij = P.H * vdotr * (iw * rhoij);
-            mumax = fmax(mumax, muij);
-            double vg = Vx * gx + Vy * gy;
-            if (DIM == 3) vg += Vz * gz;
-            if (XSPH) {
-                /* viscosity only for approaching pairs (WCXSPH3D.cpp:175-178): mu has the sign
-                 * of vdotr, and a zero factor gives the same zero */
-                const double pifac = P.alpha * cbar * fmin(muij, 0.0) * inv_rho;
-                const double mj = (double)rj.m;
-                const double sc = mj * (pifac - ri.prr - rj.prr);
-                acc0 += gx * sc;
-                acc1 += gy * sc;
-                if (DIM == 3) acc2 += gz * sc;
-                const double xs = P.eps * (mj * inv_rho) * Kern;
-                Vs0 += xs * Vx;
-                Vs1 += xs * Vy;
-                if (DIM == 3) Vs2 += xs * Vz;
-                rr -= mj * vg;
-            } else {
-                const double pifac = -P.alpha * cbar * fmin(muij, 0.0) * inv_rho;
-                const double sc = pifac + ri.prr + rj.prr;
-                acc0 -= gx * sc;
-                acc1 -= gy * sc;
-                rr -= vg;
+    for (uint32_t g = 0; g < PAIR_GROUPS; ++g) {
+        const uint32_t gbase = wbase + g * PAIR_GROUP;
+        if (gbase >= end) break; /* wave-uniform */
+        const uint32_t i_raw = gbase + (uint32_t)p;
+        const bool active = i_raw < end;
+        const uint32_t i = active ? i_raw : end - 1;
+
+        /* The particle's own record: lane q loads chunk q (the wave reads 16 whole records, 1 KiB in
+         * a row) and the quad passes the pieces round. */
+        const f64x2_t own = *((const f64x2_t*)(rin + i) + q);
+        const double xi0 = quad_perm_d<0x00>(own.x), vi0 = quad_perm_d<0x00>(own.y);
+        const double xi1 = quad_perm_d<0x55>(own.x), vi1 = quad_perm_d<0x55>(own.y);
+        const double xi2 = quad_perm_d<0xAA>(own.x), vi2 = quad_perm_d<0xAA>(own.y);
+        const double rho_m = quad_perm_d<0xFF>(own.x); /* the floats rho and m */
+        const double prr_i = quad_perm_d<0xFF>(own.y);
+        const float rho_if = half_of(rho_m, 0u), m_if = half_of(rho_m, 1u);
+        const double rho_i = (double)rho_if;
+        const double c_i = sqrtBgam * fast_rsq(rho_i); /* sqrt(B*gam/rho), WCXSPH3D.cpp:172 */
+
+        /* The candidate row of particle i: entry e at nbr[i*cap + e].  Every fourth round each
+         * lane fetches 16 bytes of it: lane q holds the four candidates of round 4u+q.
+         * Unconditional and in bounds; entries past the count are replaced where they are used. */
+        const uint32_t* const row = nbr + (size_t)i * stride;
+        auto fetch_vec = [&](uint32_t u) -> uint4 {
+            const uint32_t e = u * 16u + (uint32_t)q * 4u;
+            const u32x4_t v = stream_load((const u32x4_t*)(row + (e < last_group ? e : last_group)));
+            return make_uint4(v.x, v.y, v.z, v.w);
+        };
+        /* the count and the head of the candidate row are requested together with the record */
+        const uint32_t c = active ? stream_load(cnt + i) : 0u;
+        const uint4 vhead = fetch_vec(0);
+        const uint4 vhead1 = fetch_vec(1);
+        /* rounds of four candidates; the trip count is made wave-uniform */
+        const uint32_t rounds = __builtin_amdgcn_readfirstlane(quads_allmax((c + 3u) >> 2));
+
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+        double Vs0 = 0.0, Vs1 = 0.0, Vs2 = 0.0;
+        double rr = 0.0, mumax = 0.0;
+
+        /* The pieces go from memory into the transpose area without a stop in registers: a 16-byte
+         * global->LDS copy, every lane naming its own source, the destination the wave-uniform base
+         * plus lane*16 -- the lane-linear image the transpose reads.  The copies of round t+1 are
+         * issued once round t's records have been read out of the area (lgkmcnt) and are waited for
+         * (vmcnt) a whole round of arithmetic later. */
+        auto piece = [&](uint32_t j) -> const char* {
+            PAIR_HOOK_FETCH(j, i)
+            return !WIDE ? (const char*)rin + ((j << 6) | qoff) : (const char*)(rin + j) + 16 * q;
+        };
+        auto copy16 = [&](const char* src, char* dst_wave_base) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+        };
+        auto load4 = [&](uint32_t j0, uint32_t j1, uint32_t j2, uint32_t j3) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the area has been read */
+            copy16(piece(j0), wstage);
+            copy16(piece(j1), wstage + 1 * PAIR_LDS_BLOCK + 16);
+            copy16(piece(j2), wstage + 2 * PAIR_LDS_BLOCK + 32);
+            copy16(piece(j3), wstage + 3 * PAIR_LDS_BLOCK + 48);
+        };
+        /* load round t, whose four candidates sit in lane (t & 3) of the quad */
+#define LOAD_FROM(VEC, R, T)                                                        \
+        {                                                                               \
+            const uint32_t a0 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).x);           \
+            const uint32_t a1 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).y);           \
+            const uint32_t a2 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).z);           \
+            const uint32_t a3 = (uint32_t)quad_perm_i<(R)*0x55>((int)(VEC).w);           \
+            /* a quad whose row ends before this round fetches nothing (a wave runs as many rounds  \
+             * as its longest row needs); within a row's last round the entries past the count are  \
+             * stale or zero but always index the arrays (the lists are cleared when allocated),   \
+             * and what is fetched for them is never used */                                        \
+            if (4u * (T) < c) load4(a0, a1, a2, a3);                                                \
+        }
+        auto exchange = [&]() -> Rec {
+            /* the copies left a round ago; the vector-memory counter also covers them */
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return *(const Rec*)(wstage + q * PAIR_LDS_BLOCK + q * 16 + p * 64);
+        };
+
+        const int my_limit = (int)c - q; /* lane q holds entry 4t+q of round t: valid while 4t < c-q */
+        auto pair_term = [&](uint32_t t, const Rec& rj) {
+            const bool valid = (int)(t * 4u) < my_limit;
+            const double Rx = rj.xv[0][0] - xi0, Ry = rj.xv[1][0] - xi1;
+            const double Rz = DIM == 3 ? rj.xv[2][0] - xi2 : 0.0;
+            const double d2 = dist2_exact(Rx, Ry, Rz);
+            bool hit = valid && d2 < P.R2;
+            PAIR_HOOK_HIT(hit, t)
+            hits += (uint32_t)__popcll(__ballot(hit));
+            if (hit) {
+                const double Vx = rj.xv[0][1] - vi0, Vy = rj.xv[1][1] - vi1;
+                const double Vz = DIM == 3 ? rj.xv[2][1] - vi2 : 0.0;
+                const double r = fast_sqrt(d2);
+                const double qq = r * invH;
+                /* W2Kernel / W2GradK vanish for q >= 2 (WCXSPH3D.cpp:124,133): the clamp makes the
+                 * factor (1 - q/2) an exact zero there */
+                const double t1 = fmax(1.0 - 0.5 * qq, 0.0);
+                const double t2 = t1 * t1;
+                const double gs = gconst * (t2 * t1);
+                const double Kern = XSPH ? (t2 * t2) * (2.0 * qq + 1.0) * P.correc : 0.0;
+                const double gx = Rx * gs, gy = Ry * gs, gz = Rz * gs;
+                const double rho_j = (double)rj.rho;
+                const double cbar = 0.5 * (c_i + sqrtBgam * fast_rsq(rho_j));
+                double vdotr = Vx * Rx + Vy * Ry;
+                if (DIM == 3) vdotr += Vz * Rz;
+                const double rhoij = 0.5 * (double)(rho_if + rj.rho); /* float add, as the reference */
+                const double den = d2 + P.hvisc;
+                const double iw = fast_rcp(den * rhoij);
+                const double inv_rho = iw * den;
+                const double muij = P.H * vdotr * (iw * rhoij);
+                mumax = fmax(mumax, muij);
+                double vg = Vx * gx + Vy * gy;
+                if (DIM == 3) vg += Vz * gz;
+                if (XSPH) {
+                    /* viscosity only for approaching pairs (WCXSPH3D.cpp:175-178): mu has the sign
+                     * of vdotr, and a zero factor gives the same zero */
+                    const double pifac = P.alpha * cbar * fmin(muij, 0.0) * inv_rho;
+                    const double mj = (double)rj.m;
+                    const double sc = mj * (pifac - prr_i - rj.prr);
+                    acc0 += gx * sc;
+                    acc1 += gy * sc;
+                    if (DIM == 3) acc2 += gz * sc;
+                    const double xs = P.eps * (mj * inv_rho) * Kern;
+                    Vs0 += xs * Vx;
+                    Vs1 += xs * Vy;
+                    if (DIM == 3) Vs2 += xs * Vz;
+                    rr -= mj * vg;
+                } else {
+                    const double pifac = -P.alpha * cbar * fmin(muij, 0.0) * inv_rho;
+                    const double sc = pifac + prr_i + rj.prr;
+                    acc0 -= gx * sc;
+                    acc1 -= gy * sc;
+                    rr -= vg;
+                }
+            }
+        };
+
+        /* Round t: pass its pieces through LDS, start the loads of round t+1, then do the
+         * arithmetic of round t while they fly.  R = t & 3 is spelled out because the lane
+         * pattern of a cross-lane move is part of the instruction. */
+#define ROUND(R, NEXTVEC, NEXTR)                               \
+        {                                                          \
+            const uint32_t t = u * 4u + (R);                       \
+            if (t >= rounds) break;                                \
+            const Rec rj = exchange();                             \
+            if (t + 1 < rounds) LOAD_FROM(NEXTVEC, NEXTR, t + 1)   \
+            pair_term(t, rj);                                      \
+        }
+
+        if (rounds > 0) {
+            /* the entries of rounds 0..7 were requested with the rest up front; those of super-round
+             * u+2 are requested at the top of super-round u, so that the wait for a round's records
+             * (the counter is in order) never includes a row fetch that has just left */
+            uint4 vcur = vhead, vnext = vhead1;
+            LOAD_FROM(vcur, 0, 0u)
+            const uint32_t nsup = (rounds + 3u) >> 2;
+            for (uint32_t u = 0; u < nsup; ++u) {
+                uint4 vafter = vnext;
+                ROUND(0, vcur, 1)
+                /* behind round 1's copies, so a round old at the next wait */
+                if (u + 2 < nsup) vafter = fetch_vec(u + 2);
+                ROUND(1, vcur, 2)
+                ROUND(2, vcur, 3)
+                ROUND(3, vnext, 0)
+                vcur = vnext;
+                vnext = vafter;
             }
         }
-    };
-
-    /* Round t: pass its pieces through LDS, start the loads of round t+1, then do the
-     * arithmetic of round t while they fly.  R = t & 3 is spelled out because the lane
-     * pattern of a cross-lane move is part of the instruction. */
-#define ROUND(R, NEXTVEC, NEXTR)                               \
-    {                                                          \
-        const uint32_t t = u * 4u + (R);                       \
-        if (t >= rounds) break;                                \
-        const Rec rj = exchange();                             \
-        if (t + 1 < rounds) LOAD_FROM(NEXTVEC, NEXTR, t + 1)   \
-        pair_term(t, rj);                                      \
-    }
-
-    PHASE_MARK(1)
-    if (rounds > 0) {
-        /* the entries of rounds 0..7 were requested with the rest up front; those of super-round
-         * u+2 are requested at the top of super-round u, so that the wait for a round's records
-         * (the counter is in order) never includes a row fetch that has just left */
-        uint4 vcur = vhead, vnext = vhead1;
-        LOAD_FROM(vcur, 0, 0u)
-        const uint32_t nsup = (rounds + 3u) >> 2;
-        for (uint32_t u = 0; u < nsup; ++u) {
-            uint4 vafter = vnext;
-            ROUND(0, vcur, 1)
-            /* behind round 1's copies, so a round old at the next wait */
-            if (u + 2 < nsup) vafter = fetch_vec(u + 2);
-            ROUND(1, vcur, 2)
-            ROUND(2, vcur, 3)
-            ROUND(3, vnext, 0)
-            vcur = vnext;
-            vnext = vafter;
-        }
-    }
 #undef ROUND
 #undef LOAD_FROM
-    PHASE_MARK(2)
 
-    /* quad totals */
-    acc0 = quad_sum(acc0); acc1 = quad_sum(acc1);
-    if (DIM == 3) acc2 = quad_sum(acc2);
-    if (XSPH) {
-        Vs0 = quad_sum(Vs0); Vs1 = quad_sum(Vs1);
-        if (DIM == 3) Vs2 = quad_sum(Vs2);
-    }
-    rr = quad_sum(rr);
-    mumax = quad_max(mumax);
-
-    /* lane d finishes component d; lane 3 the scalars */
-    const bool wall = zero_wall && my_id < P.bound_parts;
-    double f2 = 0.0, move2 = 0.0;
-    double fd = q == 0 ? acc0 : (q == 1 ? acc1 : acc2);
-    double Vd = (q == 0 ? vi0 : (q == 1 ? vi1 : vi2)) + (q == 0 ? Vs0 : (q == 1 ? Vs1 : Vs2));
-    if (!XSPH) fd *= P.mass;
-    if (q == P.g_axis) fd += P.g;
-    float Rrho_f = XSPH ? (float)rr : (float)(rr * P.mass);
-    if (wall) { /* WCXSPH3D.cpp:260-264 */
-        fd = 0.0;
-        Vd = 0.0;
-    }
-    if (q >= DIM) fd = 0.0;
-    if (active && store_out) {
-        if (q < DIM) {
-            stream_store(pick3(out.f, q) + i, fd);
-            if (XSPH) stream_store(pick3(out.V, q) + i, Vd);
-        } else if (q == 3) {
-            stream_store(out.Rrho + i, Rrho_f);
+        /* quad totals, left for the finish by the quad's first lane: particle s = 16g+p of the wave */
+        acc0 = quad_sum(acc0); acc1 = quad_sum(acc1);
+        if (DIM == 3) acc2 = quad_sum(acc2);
+        if (XSPH) {
+            Vs0 = quad_sum(Vs0); Vs1 = quad_sum(Vs1);
+            if (DIM == 3) Vs2 = quad_sum(Vs2);
+        }
+        rr = quad_sum(rr);
+        mumax = quad_max(mumax);
+        const float Rrho_f = XSPH ? (float)rr : (float)(rr * P.mass);
+        if (q == 0) {
+            const uint32_t s = g * PAIR_GROUP + (uint32_t)p;
+            wkeep[0][s] = acc0;
+            wkeep[1][s] = acc1;
+            wkeep[2][s] = acc2;
+            wkeep[3][s] = vi0 + Vs0; /* XSPH: V = v + eps*sum (WCXSPH3D.cpp:149,188) */
+            wkeep[4][s] = vi1 + Vs1;
+            wkeep[5][s] = vi2 + Vs2;
+            wkeep[6][s] = __longlong_as_double(
+                (long long)(((unsigned long long)__float_as_uint(m_if) << 32) | (unsigned long long)__float_as_uint(Rrho_f)));
+            wkeep[7][s] = mumax;
+            wkeep[8][s] = xi0;
+            wkeep[9][s] = xi1;
+            wkeep[10][s] = xi2;
         }
     }
+
+    /* ---- the finish: lane 4p+q takes particle s = 16q+p of the wave's 64 ---- */
+    const uint32_t s = (uint32_t)q * PAIR_GROUP + (uint32_t)p;
+    const uint32_t e_raw = wbase + s;
+    const bool mine = e_raw < end;
+    const uint32_t e = mine ? e_raw : end - 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* what the quads left is in place */
+    double fd[3], Vd[3], xo[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        fd[d] = wkeep[d][s];
+        Vd[d] = wkeep[3 + d][s];
+        xo[d] = wkeep[8 + d][s];
+    }
+    const double rm = wkeep[6][s];
+    const float Rrho_f = half_of(rm, 0u), m_f = half_of(rm, 1u);
+    const double mumax = mine ? wkeep[7][s] : 0.0;
+    const bool wall = zero_wall && id[e] < P.bound_parts;
+    double f2 = 0.0, move2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        if (!XSPH) fd[d] *= P.mass;
+        if (d == P.g_axis) fd[d] += P.g;
+        if (wall) { /* WCXSPH3D.cpp:260-264 */
+            fd[d] = 0.0;
+            Vd[d] = 0.0;
+        }
+        if (mine && store_out) {
+            stream_store(out.f[d] + e, fd[d]);
+            if (XSPH) stream_store(out.V[d] + e, Vd[d]);
+        }
+    }
+    if (mine && store_out) stream_store(out.Rrho + e, Rrho_f);
     if (FUSED) {
-        f2 = fd * fd;
         /* WCXSPH3D.cpp:271-277 */
-        const double dt = S->dt;
         const double hdt = 0.5 * dt;
         const double dt2 = dt * dt;
-        union { double d[2]; float f[4]; } chunk;
-        if (q < DIM) {
-            const double fn = n0;
-            const double vn = n1;
-            const double adv = XSPH ? n2 : vn;
-            const double c1 = 0.5 * dt2 * P.omb;
-            const double c2 = dt2 * P.beta;
-            const double xnew = n3 + dt * adv + c1 * fn + c2 * fd;
-            chunk.d[0] = xnew;
-            chunk.d[1] = vn + hdt * (fn + fd);
-            const double ex = xnew - (q == 0 ? xi0 : (q == 1 ? xi1 : xi2));
-            move2 = ex * ex;
-        } else if (q == 3) {
-            const float Rrho_n = half_of(n0, i & 1u), rho_n = half_of(n1, i & 1u);
-            const float rsum = Rrho_n + Rrho_f; /* float add, as the reference */
-            const float rho_new = (float)((double)rho_n + hdt * (double)rsum);
-            const float p_new = (float)(P.B * tait_pow_m1((double)rho_new / P.rho0, P.gam));
-            chunk.f[0] = rho_new;
-            chunk.f[1] = ri.m;
-            chunk.d[1] = (double)p_new / ((double)rho_new * (double)rho_new);
-            if (active) stream_store(pout + i, p_new);
-        } else { /* the unused component of a 2-D run stays zero */
-            chunk.d[0] = 0.0;
-            chunk.d[1] = 0.0;
+        const double c1 = 0.5 * dt2 * P.omb;
+        const double c2 = dt2 * P.beta;
+        f64x2_t w[4];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            w[d].x = 0.0; /* the unused component of a 2-D run stays zero */
+            w[d].y = 0.0;
+            if (d < DIM) {
+                const double fn = stream_load(ns.f[d] + e);
+                const double vn = stream_load(ns.v[d] + e);
+                const double adv = XSPH ? stream_load(ns.V[d] + e) : vn;
+                const double xn = stream_load(ns.x[d] + e);
+                const double xnew = xn + dt * adv + c1 * fn + c2 * fd[d];
+                w[d].x = xnew;
+                w[d].y = vn + hdt * (fn + fd[d]);
+                const double ex = xnew - xo[d];
+                f2 += fd[d] * fd[d];
+                move2 += ex * ex;
+            }
         }
-        if (active) {
-            f64x2_t w;
-            w.x = chunk.d[0];
-            w.y = chunk.d[1];
-            stream_store((f64x2_t*)(rout + i) + q, w);
+        const float Rrho_n = stream_load(ns.Rrho + e), rho_n = stream_load(ns.rho + e);
+        const float rsum = Rrho_n + Rrho_f; /* float add, as the reference */
+        const float rho_new = (float)((double)rho_n + hdt * (double)rsum);
+        const float p_new = (float)(P.B * tait_pow_m1((double)rho_new / P.rho0, P.gam));
+        w[3].x = __longlong_as_double(
+            (long long)(((unsigned long long)__float_as_uint(m_f) << 32) | (unsigned long long)__float_as_uint(rho_new)));
+        w[3].y = (double)p_new / ((double)rho_new * (double)rho_new);
+        if (mine) stream_store(pout + e, p_new);
+        /* The new records leave as whole kilobytes: particle s lays its four chunks into the
+         * transpose area (block s/16, record s%16), and the wave stores each block lane-linear --
+         * 16 whole records per instruction. */
+        char* const slot = wstage + q * PAIR_LDS_BLOCK + p * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(f64x2_t*)(slot + 16 * k) = w[k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int b = 0; b < PAIR_GROUPS; ++b) {
+            const uint32_t t_raw = wbase + (uint32_t)b * PAIR_GROUP + (uint32_t)p; /* record p of block b, chunk q */
+            const f64x2_t v = *(const f64x2_t*)(wstage + b * PAIR_LDS_BLOCK + lane * 16);
+            if (t_raw < end) stream_store((f64x2_t*)(rout + t_raw) + q, v);
         }
-        f2 = quad_sum(f2);
-        move2 = quad_sum(move2);
+        if (!mine) {
+            f2 = 0.0;
+            move2 = 0.0;
+        }
     }
 
-    PHASE_MARK(3)
-    /* block reductions: max(mu), max |f|^2, max move^2, sum move^2, pair count; lane 0 of each
-     * quad speaks for the particle, so the butterflies start at distance 4 */
+    /* block reductions: max(mu), max |f|^2, max move^2, sum move^2, pair count */
     __shared__ double red[PAIR_BLOCK / 64][5];
-    const bool speak = active && q == 0;
-    auto quads_max = [](double v) {
-#pragma unroll
-        for (int o = 32; o >= 4; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-        return v;
-    };
-    auto quads_sum = [](double v) {
-#pragma unroll
-        for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o);
-        return v;
-    };
-    const double wm = quads_max(speak ? mumax : 0.0);
+    const double wm = wave_allmax(mumax);
     if (FUSED) {
-        const double wf = quads_max(speak ? f2 : 0.0);
-        const double wv = quads_max(speak ? (move2 == move2 ? move2 : 1e300) : 0.0); /* NaN counts as huge */
-        const double ws = quads_sum(speak ? move2 : 0.0);
+        const double wf = wave_allmax(f2);
+        const double wv = wave_allmax(move2 == move2 ? move2 : 1e300); /* NaN counts as huge */
+        const double ws = wave_allsum(move2);
         const double wh = (double)hits;
         if (lane == 0) {
             red[wave][0] = wm; red[wave][1] = wf; red[wave][2] = wv; red[wave][3] = ws; red[wave][4] = wh;
@@ -1242,7 +1339,7 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
         red[wave][0] = wm;
     }
     __syncthreads();
-    /* no atomics: with hundreds of thousands of workgroups, adds to one word serialise at the
+    /* no atomics: with tens of thousands of workgroups, adds to one word serialise at the
      * memory side.  Each workgroup leaves its five partials; two small kernels fold them. */
     if (threadIdx.x == 0) {
         double a = red[0][0];
@@ -1251,30 +1348,19 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
         part += part_base;
         part[block] = a;
         if (FUSED) {
-            double b = red[0][1], c2 = red[0][2], s = red[0][3], h = red[0][4];
+            double b = red[0][1], c2 = red[0][2], sm = red[0][3], h = red[0][4];
             for (int w = 1; w < PAIR_BLOCK / 64; ++w) {
                 b = fmax(b, red[w][1]);
                 c2 = fmax(c2, red[w][2]);
-                s += red[w][3];
+                sm += red[w][3];
                 h += red[w][4];
             }
             part[nb + block] = b;
             part[2 * (size_t)nb + block] = c2;
-            part[3 * (size_t)nb + block] = s;
+            part[3 * (size_t)nb + block] = sm;
             part[4 * (size_t)nb + block] = h;
         }
     }
-#ifdef SPH_PHASE_TIMING
-    if (FUSED && (blockIdx.x & 63u) == 0 && lane == 0 && rounds >= 7) { /* fluid waves */
-        const unsigned long long tend = __builtin_amdgcn_s_memtime();
-        atomicAdd(&g_phase[0], tmark1 - tmark0);
-        atomicAdd(&g_phase[1], tmark2 - tmark1);
-        atomicAdd(&g_phase[2], tmark3 - tmark2);
-        atomicAdd(&g_phase[3], tend - tmark3);
-        atomicAdd(&g_phase[4], (unsigned long long)rounds);
-        atomicAdd(&g_phase[7], 1ull);
-    }
-#endif
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1911,20 +1997,6 @@ struct shared_divisor {
     }
 };
 
-/* x + (x moved by W lanes to its partner block), W = 16 or 32, for a double */
-template <int W>
-__device__ __forceinline__ double rows_pair_sum(double x) {
-    const uint32_t lo = (uint32_t)__double2loint(x), hi = (uint32_t)__double2hiint(x);
-    if (W == 16) {
-        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
-    }
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
-}
-
 /* Ten wave-wide sums at once (the upper triangle of the 3-D moment matrix): instead of ten
  * butterflies of six steps, every step folds PAIRS of values, each keeping its half of the lanes
  * -- the sum of a in the lower half, of b in the upper -- so the work halves with the lane
@@ -1974,25 +2046,9 @@ __device__ __forceinline__ void wave_allsum10(double (&v)[10]) {
 }
 
 /* One wavefront per released particle: the lanes share out its candidates, partial sums are
- * folded with a fixed butterfly (every lane ends with the same bits), every lane solves the
- * small system, lane 0 stores rho, and each lane releases the waiting neighbours among its
- * candidates. */
-__device__ __forceinline__ double wave_allsum(double v) {
-    /* inside a row of sixteen lanes by data-parallel-primitive moves (a few cycles each, against
-     * an LDS round trip for a cross-lane read): partners 1 and 2 apart in the quad, then the
-     * mirror image within eight and within sixteen lanes -- after the quad steps every lane of a
-     * quad holds the quad's sum, so the mirror pairs whole quads.  Then across the four rows. */
-    v += quad_perm_d<QP_XOR1>(v);
-    v += quad_perm_d<QP_XOR2>(v);
-    v += quad_perm_d<0x141>(v); /* row_half_mirror */
-    v += quad_perm_d<0x140>(v); /* row_mirror */
-    /* across the four rows: swap the odd rows of one copy with the even rows of another (vector
-     * ALU, no trip through the LDS crossbar); the two copies then hold, lane by lane, the two
-     * rows to be added -- the same two numbers as a shuffle by 16, then by 32, would pair */
-    v = rows_pair_sum<16>(v);
-    v = rows_pair_sum<32>(v);
-    return v;
-}
+ * folded with a fixed butterfly (wave_allsum: every lane ends with the same bits), every lane
+ * solves the small system, lane 0 stores rho, and each lane releases the waiting neighbours among
+ * its candidates. */
 
 /* What the one-launch walk hands to reinit_one: where finished particles publish their rho
  * ({rho, tag} in one 8-byte word, tag = the number of this DensityReinit call), the stop flag

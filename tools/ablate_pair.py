@@ -1,5 +1,5 @@
 """Timing experiment: the pair launch of the benchmark case (lattice at rest) with a library built
-with -DSPH_ABLATE=n (1: every fetch aimed at the particle's own record, 2: the arithmetic of every
+with -include tools/pair_hooks.h -DSPH_ABLATE=n (1: every fetch aimed at the particle's own record, 2: the arithmetic of every
 other round skipped, 3: both).  Results of such a library are wrong on purpose; only the launch
 time is read.  SPH_AMD_LIB chooses the library."""
 import os, sys
