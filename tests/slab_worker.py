@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--even-planes", type=int, default=0, help="cut the box evenly in x instead of by load")
     ap.add_argument("--rebalance", type=int, default=0, help="re-cut the planes every this many steps")
     ap.add_argument("--reinit", type=int, default=0, help="DensityReinit after every this many steps")
+    ap.add_argument("--halo-room", type=int, default=0,
+                    help="room for halo and migrated particles (0: 4096 when planes are re-cut, the library's choice otherwise)")
     ap.add_argument("--transport", default="host", help="host: host-buffer callbacks; device: device-buffer callbacks")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
@@ -43,7 +45,7 @@ def main():
     if args.even_planes:
         planes = [-np.inf] + [case.box[0] * r / world for r in range(1, world)] + [np.inf]
     sim = domain.SlabSim.from_case(case, rank, world, planes=planes, device=0, migrate=bool(args.migrate),
-                                   halo_room=(1 << 12) if args.rebalance else None, **over)
+                                   halo_room=args.halo_room or ((1 << 12) if args.rebalance else None), **over)
     tr = domain.DeviceTransport(rank, world) if args.transport == "device" else domain.HostTransport(rank, world)
     sim.set_transport(tr.struct)
     if args.jitter > 0:

@@ -107,6 +107,49 @@ def test_fullsize_neighbour_counts_do_not_depend_on_knobs(big):
     other.close()
 
 
+def test_c4_on_one_gpu_t0_first_sweep_and_neighbour_counts():
+    """The >=100 M-particle configuration (fluid 2048x1024x48 + walls = 121.5 M particles) fits one
+    GPU: the same known answers as at C3 -- f = g at t = 0, the first sweep's closed form bit for
+    bit, every particle its own neighbour and the 27-point lattice stencil present."""
+    sim = capi.Sim.from_case(dam_break(2048, 1024, 48))
+    try:
+        assert sim.npts > 100_000_000
+        nb = sim.bound_parts
+        x0 = sim.download(capi.STATE_N, names=("x",))["x"]
+        sim.forces(capi.STATE_N)
+        sim.zero_boundary_forces(capi.STATE_N)
+        st = sim.download(capi.STATE_N, names=("f", "V", "Rrho"))
+        assert not st["f"][:, :nb].any()
+        assert not st["f"][:2, nb:].any() and np.all(st["f"][2, nb:] == -9.81)
+        assert not st["Rrho"].any() and not st["V"].any()
+        assert sim.scalars()["maxmu"] == 0.0
+        del st
+
+        offs = np.zeros(sim.npts + 1, np.uint64)
+        sim._chk(capi.lib().sph_neighbours(sim._h, capi.STATE_N, offs.ctypes.data, None), "sph_neighbours")
+        counts = np.diff(offs.astype(np.int64))
+        assert (int(offs[-1]) - sim.npts) % 2 == 0
+        assert counts.min() >= 1 and 27 in counts[nb:nb + 4_000_000]
+        del offs, counts
+
+        sc = sim.sweeps(1)
+        st = sim.download(capi.STATE_NP1, names=("x", "v", "rho", "p"))
+        dt, g = 0.0002, -9.81
+        beta = np.float32(0.25)
+        c1 = 0.5 * (dt * dt) * float(np.float32(1) - np.float32(2) * beta)
+        c2 = dt * dt * float(beta)
+        assert np.all(st["v"][2, nb:] == 0.0 + 0.5 * dt * (g + g))
+        assert not st["v"][:2].any() and not st["v"][:, :nb].any()
+        assert np.all(st["x"][2, nb:] == x0[2, nb:] + dt * 0.0 + c1 * g + c2 * g)
+        assert np.array_equal(st["x"][:2], x0[:2]) and np.array_equal(st["x"][:, :nb], x0[:, :nb])
+        assert np.all(st["rho"] == np.float32(1000.0)) and not st["p"].any()
+        d = (c1 * g + c2 * g)
+        n_fluid = sim.npts - nb
+        assert abs(sc["errsum"] - n_fluid * d * d) <= 1e-6 * n_fluid * d * d
+    finally:
+        sim.close()
+
+
 # ---- 2-D WCSPH at ~1 M particles (single mass, no XSPH, radius^2 = 4 H^2 + 0.001 H) -------------
 
 def dam_break_2d():

@@ -209,3 +209,67 @@ def test_settings_summary_against_the_file_the_reference_ships(tmp_path):
         assert mine[k] == golden[k], (k, mine[k], golden[k])
     assert mine[1] == "\tNumber of frames (1)" and golden[1] == "\tNumber of frames (2000)"
     assert mine[8] == "\tGravitational strength (9.81)" and mine[9] == "\tNumber of boundary points (660)"
+
+
+def _broken_settings(tmp_path, name, extra):
+    """A run whose first step destroys the fluid: with dt = 1e200, dt*dt overflows and the update
+    x + dt*V + (dt*dt/2)(1-2 beta) f forms infinity * 0 in the components gravity does not act on."""
+    spec = util.small_cases()["wcxsph3d_block"]
+    fmt = lambda a: " ".join(repr(float(v)) for v in a)
+    path = tmp_path / (name + ".txt")
+    path.write_text("\n".join([
+        "default_params? no", "outfile %s" % (tmp_path / name), "program WCXSPH3D", "nframes 4", "npframe 1",
+        "dt 1e200", "psize %r" % spec["pstep"], "rho_ref 1000", "viscosity 0.025", "gravity 9.81", "simtype Box",
+        "npart " + " ".join(str(v) for v in spec["npart"]), "box " + fmt(spec["box"]), "start " + fmt(spec["start"]),
+        "reinit 0", "device 0"] + extra + [""]))
+    return str(path)
+
+
+def _check_broken_plt(path, bound_parts):
+    """Frame 0 whole; frame 1 with its wall zone and the header of its particle zone, cut at the
+    first broken fluid row (the first one: every fluid particle is hit); nothing after it."""
+    header, zones = parse_plt(path)
+    assert header.startswith("VARIABLES")
+    assert [z[0] for z in zones] == ["Boundary Data", "Particle Data", "Boundary Data", "Particle Data"]
+    assert zones[0][2].shape[0] == bound_parts and zones[2][2].shape[0] == bound_parts
+    assert zones[1][2].shape[0] > 0 and zones[3][2].size == 0
+    assert open(path, "rb").read().endswith(b"\n")
+
+
+def test_a_run_that_goes_nan_stops_like_the_reference(tmp_path):
+    # WCXSPH3D.cpp:422-431: the row is reported on stderr, the file is closed, exit(-1)
+    r = subprocess.run([SPH_RUN, _broken_settings(tmp_path, "Nan", [])], capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0, r.stdout + r.stderr
+    assert "Simulation is broken. A value is nan." in r.stderr and "Broken line..." in r.stderr
+    assert "nan" in r.stderr.split("Broken line...")[1].lower()
+    assert "Frame Number: 1\tError:" in r.stdout and "Simulation complete." not in r.stdout
+    spec = util.small_cases()["wcxsph3d_block"]
+    oc, _ = util.both_cases(spec)
+    orc = O.Oracle(oc)
+    _check_broken_plt(str(tmp_path / "Nan.plt"), orc.bound_parts)
+    orc.close()
+
+
+def test_a_run_that_goes_nan_stops_on_both_ranks(tmp_path):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cfg = _broken_settings(tmp_path, "Nan2", ["transport host", "migrate 1"])
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", SPH_WIRE_PORT=str(port))
+        procs.append(subprocess.Popen([SPH_RUN, cfg], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        o, _ = p.communicate(timeout=240)  # neither rank may be left waiting for the other
+        outs.append(o)
+    assert all(p.returncode != 0 for p in procs), "\n-----\n".join(outs)
+    assert "Simulation is broken. A value is nan." in outs[0]
+    assert "Simulation complete." not in outs[0]
+    spec = util.small_cases()["wcxsph3d_block"]
+    oc, _ = util.both_cases(spec)
+    orc = O.Oracle(oc)
+    _check_broken_plt(str(tmp_path / "Nan2.plt"), orc.bound_parts)
+    orc.close()

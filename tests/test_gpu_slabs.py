@@ -31,7 +31,7 @@ def free_port():
 
 
 def run_slabs(spec, nranks, tmp_path, steps=2, skin=0.0, jitter=0.0, vx=0.0, migrate=1, even_planes=0, rebalance=0,
-              transport="host", reinit=0):
+              transport="host", reinit=0, halo_room=0):
     out = str(tmp_path / "slabs.npz")
     port = free_port()
     procs = []
@@ -41,7 +41,7 @@ def run_slabs(spec, nranks, tmp_path, steps=2, skin=0.0, jitter=0.0, vx=0.0, mig
         cmd = [sys.executable, "-u", os.path.join(HERE, "slab_worker.py"), "--spec", json.dumps(spec),
                "--steps", str(steps), "--skin", str(skin), "--jitter", str(jitter), "--vx", str(vx),
                "--migrate", str(migrate), "--even-planes", str(even_planes), "--rebalance", str(rebalance),
-               "--reinit", str(reinit), "--transport", transport, "--out", out]
+               "--reinit", str(reinit), "--halo-room", str(halo_room), "--transport", transport, "--out", out]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs, bad = [], False
     for p in procs:
@@ -229,6 +229,42 @@ def test_medium_size_slabs_against_the_single_domain(nranks, tmp_path):
     assert res["scalars"][6] == sc["hit_pairs"]
     assert res["per_rank"].min() > 50_000
     sim.close()
+
+
+def test_two_million_particle_droplet_on_two_slabs(tmp_path):
+    # The droplet configuration at the benchmark's spacing, 2.1 M particles: a sphere of 3.1 m
+    # radius moving down onto a 32 x 20 x 2.5 m pool, its underside within reach of the surface
+    # from the first sweep.  Too large for the CPU oracle, so the bar is the single-domain HIP
+    # path (itself checked against the oracle on the smaller droplet cases above): neighbour
+    # sets identical, every field finite and within the usual bars, no particle lost while the
+    # planes are cut evenly and re-cut by load every other step.
+    from sph_amd import capi
+    drop = dict(simtype=1, radius=3.1, centre=(16.0, 10.0, 5.75), v=(0.6, 0.0, -2.0))
+    spec = dict(program=2, npart=(320, 200, 25), pstep=0.1, box=(32.3, 20.3, 12.0), start=(0.15, 0.15, 0.15), drop=drop)
+    steps = 4
+    res = run_slabs(spec, 2, tmp_path, steps=steps, even_planes=1, rebalance=2, halo_room=1 << 17)
+    _, pc = util.both_cases(spec)
+    sim = capi.Sim.from_case(pc)
+    assert sim.npts > 2_000_000
+    sim.forces(capi.STATE_N)
+    f0 = sim.download(capi.STATE_N, names=("f", "V", "Rrho"))
+    offs, cols = sim.neighbours(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    sc = sim.step(steps)
+    st = sim.download(capi.STATE_N)
+    sim.close()
+    assert np.array_equal(res["nbr_offs"], offs.astype(np.int64)) and np.array_equal(res["nbr_cols"], cols)
+    for k in ("f", "V"):
+        assert util.rel_err(res["forces_" + k], f0[k]) <= TOL, k
+    for k in ("x", "v", "V", "f"):
+        assert np.isfinite(res["step_" + k]).all(), k
+        assert util.rel_err(res["step_" + k], st[k]) <= TOL, k
+    for k in ("rho", "p"):
+        assert util.float_ulp_diff(res["step_" + k], st[k]).max() <= 1, k
+    assert res["scalars"][6] == sc["hit_pairs"] and sc["hit_pairs"] > 20 * 1_000_000
+    before, after = res["counts_before"].astype(np.int64), res["moved"][:, 0].astype(np.int64)
+    assert after.sum() == before.sum() == st["rho"].shape[0]
+    assert res["moved"][:, 1].sum() == res["moved"][:, 2].sum()  # what left one rank arrived at the other
 
 
 def test_medium_size_slabs_against_the_oracle(tmp_path):
