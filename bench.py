@@ -58,10 +58,9 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(fluid, n):
-    """HBM bytes per launch of the pair kernel from the committed counter run of this same
-    workload and of THIS kernel source (rocprofv3 cannot run inside this process): FETCH_SIZE
-    with its gfx950 correction + WRITE_SIZE.  None when no counter run matches."""
+def committed_counters(fluid, n):
+    """The committed counter run of this same workload and of THIS kernel source (rocprofv3 cannot
+    run inside this process), or None when there is none that matches."""
     try:
         with open(os.path.join(ROOT, "profiles", "pair_traffic.json")) as fh:
             t = json.load(fh)
@@ -71,8 +70,24 @@ def measured_traffic(fluid, n):
         return None
     if t.get("kernel_source_sha256_16") != kernel_source_hash():
         return None
+    return t
+
+
+def measured_traffic(fluid, n):
+    """HBM bytes per launch of the pair kernel: FETCH_SIZE with its gfx950 correction + WRITE_SIZE."""
+    t = committed_counters(fluid, n)
+    if t is None:
+        return None
     reads = t["fetch_size_kib"] * 1024.0 + 0.5 * t["streamed_read_bytes_per_particle"] * n
     return reads + t["write_size_kib"] * 1024.0
+
+
+def measured_issue(fluid, n):
+    """What the pair launch keeps busy, from the same counter run: share of the SIMD-cycles in
+    which a vector instruction issues, share of the launch the address units are busy, vector
+    instructions per wave, share of their life the waves spend at a wait instruction."""
+    t = committed_counters(fluid, n)
+    return t.get("issue") if t else None
 
 
 def cpu_baseline(sample=(64, 48, 32), steps=4):
@@ -131,7 +146,19 @@ class Legs:
         elapsed, pair_ms, rb_ms, dr_ms = self.agree_max([
             elapsed, prof["pair_ms"] / launches, prof["rebuild_ms"] / max(prof["rebuilds"], 1),
             prof["pair_ms_by_kind"][2] / max(prof["pair_launches_by_kind"][2], 1)])
+        cm, cn = prof["comm_ms"], prof["comm_counts"]
+        comm = self.agree_max([cm[k] / max(cn[k], 1) for k in range(4)] + [float(c) for c in cn])
         return {
+            "comm": {
+                "what": "slowest rank: a sweep's halo exchange (HIP events on the communication stream; it runs beside the "
+                        "interior pair launch, whose time pair_ms includes the wait for it), the step's all-reduce of its "
+                        "scalars (events on the compute stream), and per list rebuild the halo set-up and the migration "
+                        "(host time, both wait for the device)",
+                "halo_exchange_ms_per_sweep": comm[0], "allreduce_ms_per_step": comm[1],
+                "halo_setup_ms_per_rebuild": comm[2], "migration_ms_per_rebuild": comm[3],
+                "halo_exchanges": int(comm[4]), "allreduces": int(comm[5]), "halo_setups": int(comm[6]),
+                "migrations": int(comm[7]),
+            },
             "elapsed": elapsed, "steps": nsteps, "ms_per_step": elapsed / nsteps * 1e3,
             "pair_ms": pair_ms, "pair_launches": prof["pair_launches"],
             "launches_on_step_lists": prof["pair_launches_by_kind"][1],
@@ -177,12 +204,16 @@ def rooflines(n_launch, n_total, dev, pairs_per_particle):
     ach_tf = f_alg / (dev["pair_ms"] * 1e-3) / 1e12
     pair = {
         "kernel": "k_pair<3,xsph,fused> (Forces + wall reset + Newmark update + EOS, one launch per sweep)",
-        "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-        "traffic": None, "algorithmic_bytes_per_launch": b_alg, "kernel_ms": dev["pair_ms"],
+        # achieved/peak/frac price the launch against the HBM roof, as the contract asks; `bound` names
+        # what the launch is held by, which is neither of the two roofs
+        "bound": "latency", "roof": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        "traffic": None, "issue": None, "algorithmic_bytes_per_launch": b_alg, "kernel_ms": dev["pair_ms"],
         "launches": dev["pair_launches"], "algorithmic_bytes_per_particle_sweep": B_ALG_PAIR + B_ALG_UPDATE,
-        "limiter": "the L1 gather rate, not bytes or flops: an instruction whose 64 lanes fetch 16 scattered 64-byte records "
-                   "passes a compute unit every 44-50 cycles whether the lines come from L1 or L2 (tools/vmem_probe.hip), "
-                   "and a wave of the launch issues about 25 of them (6.35 rounds of 4): about 1.5 ms of the launch",
+        "limiter": "neither roof binds: a round of the pair loop is a chain -- the quads' gathers land in LDS, are read back transposed, then ~100 "
+                   "FP64 instructions -- and a wave has six of them per 16 particles with one round of look-ahead: the waves "
+                   "spend over half their life at a wait instruction while the vector ALU is ~2/3 busy and the address units "
+                   "~60 %; with every gather aimed at the particle's own record the launch takes 14 % less, with half the "
+                   "arithmetic 3 % less, with both 21 % less (tools/ablate_pair.py)",
         "fp64": {"achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": ach_tf / FP64_PEAK_TFLOPS, "flop_per_pair": FLOP_PER_PAIR},
     }
@@ -252,6 +283,11 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="several GPUs: grow the case with the ranks (weak) or cut one fixed case into slabs (strong)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="several GPUs, weak scaling: skip the strong-scaling leg reported beside the headline")
+    ap.add_argument("--strong-fluid", type=str, default="",
+                    help="fluid block of the strong-scaling leg (default 2048x1024x48, the >=100 M-particle case)")
+    ap.add_argument("--strong-steps", type=int, default=10, help="timed steps of the strong-scaling leg")
     ap.add_argument("--skin", type=float, default=0.0, help="tuning: candidate-list skin fraction (0 = follow the motion)")
     ap.add_argument("--inner", type=float, default=0.0, help="tuning: step-list margin (0 = automatic, <0 = no step lists)")
     args = ap.parse_args()
@@ -266,8 +302,13 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the pair path has no CPU fallback")
-    # one GPU per rank; ranks wrap round only on a development box with fewer GPUs than ranks
-    local_rank = local_rank % torch.cuda.device_count()
+    # one GPU per rank.  Ranks may share a GPU only over the host-staged transport (a development
+    # box): RCCL refuses two ranks on one device, so say so before anything touches a GPU.
+    ndev = torch.cuda.device_count()
+    if world > ndev and os.environ.get("SPH_TRANSPORT", "rccl") != "host":
+        raise SystemExit("WORLD_SIZE=%d but %d GPU(s) visible: one rank per GPU (or SPH_TRANSPORT=host to let ranks "
+                         "share a GPU over host-staged buffers)" % (world, ndev))
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
 
     if not args.fluid:
@@ -293,6 +334,7 @@ def main():
     out["roofline"]["traffic"] = measured_traffic((nx, ny, nz), n)
     out["roofline"]["traffic_unit"] = ("bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE of this workload and this kernel "
                                        "source, profiles/pair_traffic.json; null when the committed counter run is of another)")
+    out["roofline"]["issue"] = measured_issue((nx, ny, nz), n)
     sim.close()
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()

@@ -188,6 +188,14 @@ int sph_profile_read(sph_ctx* ctx, double* pair_ms_total, uint64_t* pair_launche
  * walked the candidate lists, [1] pair launches that walked the step lists, [2] draws of the step
  * lists from the candidates.  Both arrays have three entries. */
 int sph_profile_read_kinds(sph_ctx* ctx, double* ms3, uint64_t* launches3);
+/* Slab runs, what the exchanges cost (call it BEFORE sph_profile_read, which clears the records;
+ * no counterpart in the reference, which is one process): [0] the halo exchange of a sweep, HIP
+ * events on the communication stream round the transport's send/receive, which runs beside the
+ * interior pair launch; [1] the step's agreement on its scalars (the all-reduce that takes the
+ * place of the globals maxmu, maxf, errsum: WCXSPH3D.cpp:198-200, 280-298), events on the compute
+ * stream; [2] the halo set-up of a list rebuild and [3] the migration of particles that left the
+ * slab, both host time (they wait for the device).  Sums in ms and counts. */
+int sph_profile_read_comm(sph_ctx* ctx, double* ms4, uint64_t* count4);
 
 /* ---- slab decomposition ----------------------------------------------------------------
  * No counterpart in the reference.  A rank owns the particles whose x lay in its interval at

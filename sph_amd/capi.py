@@ -24,6 +24,7 @@ SYMBOLS = (
     "sph_create", "sph_destroy", "sph_last_error", "sph_upload", "sph_download", "sph_forces",
     "sph_zero_boundary_forces", "sph_step", "sph_step_noalloc", "sph_sweeps", "sph_get_scalars", "sph_set_dt",
     "sph_density_reinit", "sph_neighbours", "sph_profile_enable", "sph_profile_read", "sph_profile_read_kinds",
+    "sph_profile_read_comm",
     "sph_case_default", "sph_case_params", "sph_case_init",
     "sph_set_transport", "sph_upload_global_ids", "sph_rccl_unique_id", "sph_use_rccl",
     "sph_case_init_range", "sph_case_histogram_x", "sph_local_count", "sph_download_global_ids",
@@ -121,6 +122,7 @@ def lib():
     L.sph_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sph_profile_read_kinds.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.sph_profile_read_comm.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sph_case_default.argtypes = [C.c_int32, C.POINTER(Case)]
     L.sph_case_params.argtypes = [C.POINTER(Case), C.POINTER(Params), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]
@@ -410,9 +412,14 @@ class Sim:
         step lists."""
         kms, kn = (C.c_double * 3)(), (C.c_uint64 * 3)()
         self._chk(lib().sph_profile_read_kinds(self._h, kms, kn), "sph_profile_read_kinds")
+        cms, cn = (C.c_double * 4)(), (C.c_uint64 * 4)()
+        self._chk(lib().sph_profile_read_comm(self._h, cms, cn), "sph_profile_read_comm")
         out = self._profile_read()
         out["pair_ms_by_kind"] = [float(v) for v in kms]
         out["pair_launches_by_kind"] = [int(v) for v in kn]
+        # slab runs: halo exchange of a sweep, the step's all-reduce, halo set-up and migration at a rebuild
+        out["comm_ms"] = [float(v) for v in cms]
+        out["comm_counts"] = [int(v) for v in cn]
         return out
 
     def _profile_read(self):

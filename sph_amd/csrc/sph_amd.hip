@@ -175,6 +175,13 @@ struct sph_ctx {
     std::vector<EventPair> rb_pool;
     size_t rb_used = 0;
     std::vector<EventPair> dr_pool; /* draws of the step lists */
+    /* slab runs: a sweep's halo exchange (on the communication stream) and a step's agreement on
+     * its scalars (on the compute stream), and the host's time in a rebuild's halo set-up and
+     * migration (both wait for the device) */
+    std::vector<EventPair> hx_pool, ar_pool;
+    size_t hx_used = 0, ar_used = 0;
+    double halo_setup_ms = 0, migrate_ms = 0;
+    uint64_t halo_setups = 0, migrations = 0;
     size_t dr_used = 0;
 };
 
@@ -660,7 +667,12 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     bool renumber = false;
     if (c->dist && c->migrate && may_migrate && src == c->b0) {
         uint32_t n_new = n;
+        const auto t0 = std::chrono::steady_clock::now();
         CHK(migrate_particles(c, src, &m_sort, &n_new));
+        if (c->profile) {
+            c->migrate_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            ++c->migrations;
+        }
         renumber = m_sort != n || n_new != n;
         drop = c->drop;
         n = n_new; /* kernels below that walk the owned particles before the sort use m_sort and drop */
@@ -900,7 +912,12 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     HIPCHK(hipGetLastError());
 
     if (c->dist) {
+        const auto t0 = std::chrono::steady_clock::now();
         CHK(exchange_halo_at_rebuild(c, src, thr_send));
+        if (c->profile) {
+            c->halo_setup_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            ++c->halo_setups;
+        }
         /* Owned particles that can see a halo particle, and all those sent to a neighbour, have
          * x <= thr_send[0] or x >= thr_send[1]: with bricks numbered x-slowest they sit in the
          * first / last few brick columns, contiguous ranges of the cell order. */
@@ -980,6 +997,20 @@ NState n_state(sph_ctx* c) {
     s.rho = c->nfl[F_RHO];
     s.Rrho = c->nfl[F_RRHO];
     return s;
+}
+
+/* An event pair from a pool that grows on demand (nullptr when not profiling, or when the pool is
+ * used up in a call that may not allocate). */
+EventPair* take_events(sph_ctx* c, std::vector<EventPair>& pool, size_t& used) {
+    if (!c->profile || (c->no_alloc && used == pool.size())) return nullptr;
+    if (used == pool.size()) {
+        EventPair e;
+        if (hipEventCreate(&e.a) != hipSuccess) return nullptr;
+        if (hipEventCreate(&e.b) != hipSuccess) { (void)hipEventDestroy(e.a); return nullptr; }
+        e.kind = 0;
+        pool.push_back(e);
+    }
+    return &pool[used++];
 }
 
 /* Launches the pair kernel over particles [first, first+count); its workgroups leave their
@@ -1121,9 +1152,12 @@ int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, uint32_t* part_n_out
     CHK(launch_sweep(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, c->iL_end, nI, bL + bR, part_n));
     /* the exchange runs beside the interior launch */
     HIPCHK(hipStreamWaitEvent(c->comm, c->ev_packed, 0));
+    EventPair* const hx = take_events(c, c->hx_pool, c->hx_used);
+    if (hx) HIPCHK(hipEventRecord(hx->a, c->comm));
     CHK(exchange_bytes(c, c->sendbuf, (size_t)c->nsend[0] * sizeof(Rec), c->recvbuf, (size_t)c->nrecv[0] * sizeof(Rec),
                        c->sendbuf + hc, (size_t)c->nsend[1] * sizeof(Rec), c->recvbuf + hc,
                        (size_t)c->nrecv[1] * sizeof(Rec)));
+    if (hx) HIPCHK(hipEventRecord(hx->b, c->comm));
     HIPCHK(hipEventRecord(c->ev_recvd, c->comm));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_recvd, 0));
     /* received records go where the halo particles live in this rank's cell order; the
@@ -1252,7 +1286,10 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
              * exchange, on the device, in stream order; the time step and the commit follow
              * from the agreed values, and the host looks at the result once */
             hipLaunchKernelGGL(k_pack_global, dim3(1), dim3(1), 0, c->stream, c->S, c->red_dev);
+            EventPair* const ar = take_events(c, c->ar_pool, c->ar_used);
+            if (ar) HIPCHK(hipEventRecord(ar->a, c->stream));
             CHK(allreduce_step_scalars(c));
+            if (ar) HIPCHK(hipEventRecord(ar->b, c->stream));
             hipLaunchKernelGGL(k_apply_global, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->red_dev, partial ? 0 : 1);
         }
         if (!partial) {
@@ -1569,6 +1606,8 @@ void sph_destroy(sph_ctx* c) {
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : c->rb_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : c->dr_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : c->hx_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : c->ar_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
     if (c->ev_recvd) (void)hipEventDestroy(c->ev_recvd);
     if (c->comm) (void)hipStreamDestroy(c->comm);
@@ -2119,6 +2158,34 @@ int sph_profile_read(sph_ctx* c, double* pair_ms, uint64_t* pair_launches, doubl
     if (rebuilds) *rebuilds = c->rb_used;
     c->rb_used = 0;
     c->dr_used = 0;
+    c->hx_used = c->ar_used = 0;
+    c->halo_setup_ms = c->migrate_ms = 0;
+    c->halo_setups = c->migrations = 0;
+    return SPH_OK;
+}
+
+int sph_profile_read_comm(sph_ctx* c, double* ms4, uint64_t* count4) {
+    if (!c || !ms4 || !count4) return SPH_EINVAL;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->comm) HIPCHK(hipStreamSynchronize(c->comm));
+    for (int k = 0; k < 4; ++k) { ms4[k] = 0; count4[k] = 0; }
+    for (size_t i = 0; i < c->hx_used; ++i) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->hx_pool[i].a, c->hx_pool[i].b));
+        ms4[0] += ms;
+    }
+    count4[0] = c->hx_used;
+    for (size_t i = 0; i < c->ar_used; ++i) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->ar_pool[i].a, c->ar_pool[i].b));
+        ms4[1] += ms;
+    }
+    count4[1] = c->ar_used;
+    ms4[2] = c->halo_setup_ms;
+    count4[2] = c->halo_setups;
+    ms4[3] = c->migrate_ms;
+    count4[3] = c->migrations;
     return SPH_OK;
 }
 

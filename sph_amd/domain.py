@@ -385,6 +385,17 @@ def bench_main(args, world, rank, local_rank, fluid):
     alli = [torch.zeros_like(info) for _ in range(world)]
     dist.all_gather(alli, info)
     n = sim.npts_global
+
+    # Beside a weak-scaling headline: the >=100 M-particle case cut into as many slabs as there are
+    # ranks, a few timed steps of developed flow, against the committed single-GPU figure of the
+    # same case -- the strong-scaling efficiency, in the same line.
+    strong_leg = None
+    if not strong and not args.no_strong:
+        sim.close()
+        sim = None
+        strong_leg = strong_scaling_leg(args, world, rank, local_rank, transport, ident if transport == "rccl" else None,
+                                        sync, agree_max, all_ok_soft=lambda err: agree_max([1.0 if err else 0.0])[0] > 0)
+
     if rank == 0:
         per = [int(c[0]) for c in alli]
         halo = [int(c[1]) for c in alli]
@@ -395,10 +406,14 @@ def bench_main(args, world, rank, local_rank, fluid):
             workload = "C3 x %d along x (weak scaling)" % world
         workload += (": WCXSPH3D dam break, Pstep 0.1, fluid %dx%dx%d + walls, box %.1fx%.1fx%.1f, developed flow, halo exchange over %s"
                      % (case.npart[0], ny, nz, case.box[0], case.box[1], case.box[2], how))
-        out = B.result_line(args, world, n, max(per), workload, rest, dev, reinit_ms, args.scaling, {
+        extra = {
             "particles_per_rank": per, "halo_particles_sent_per_rank": halo,
             "halo_bytes_per_sweep_per_rank": [64 * h for h in halo], "setup_s": setup_s,
-        })
+            "exchange": dev["comm"],
+        }
+        if strong_leg is not None:
+            extra["strong"] = strong_leg
+        out = B.result_line(args, world, n, max(per), workload, rest, dev, reinit_ms, args.scaling, extra)
         out["transport"] = transport
         if why_not_rccl:
             out["transport_note"] = "RCCL was asked for and could not be created: " + why_not_rccl
@@ -409,9 +424,86 @@ def bench_main(args, world, rank, local_rank, fluid):
         # the thread is still inside ncclCommInitRank with this context: leave the context alone
         dist.barrier()
         os._exit(4)
-    sim.close()
+    if sim is not None:
+        sim.close()
     dist.barrier()
     dist.destroy_process_group()
     watchdog.cancel()
     if why_not_rccl:
         raise SystemExit(4)
+
+
+def single_gpu_anchor(fluid):
+    """The committed single-GPU bench line of this fluid block (developed flow), for the strong-
+    scaling efficiency: (particle-steps/s, file) or (None, None)."""
+    import glob
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    best = (None, None)
+    for f in sorted(glob.glob(os.path.join(here, "*_single_gpu_bench.json"))):
+        try:
+            with open(f) as fh:
+                d = json.loads(fh.read().strip().splitlines()[-1])
+        except (OSError, ValueError, IndexError):
+            continue
+        if d.get("n_gpus") == 1 and "%dx%dx%d" % tuple(fluid) in d.get("config", {}).get("workload", ""):
+            best = (float(d["value"]), os.path.basename(f))  # the latest by name
+    return best
+
+
+def strong_scaling_leg(args, world, rank, local_rank, transport, ident_unused, sync, agree_max, all_ok_soft):
+    """One fixed case cut into `world` slabs: pre-roll, warm-up, a few timed steps.  Collective; a
+    failure on any rank is agreed on and reported in the line instead of ending the run."""
+    import bench as B
+    fluid = tuple(int(v) for v in args.strong_fluid.lower().split("x")) if args.strong_fluid else B.C4
+    err, sim = None, None
+    try:
+        case = B.dam_break_3d(*fluid)
+        sim = SlabSim.from_case(case, rank, world, device=local_rank, skin_frac=args.skin, inner_skin_frac=args.inner)
+    except Exception as e:  # agreed on below
+        err = repr(e)
+    if all_ok_soft(err):
+        if sim is not None:
+            sim.close()
+        return {"error": err or "another rank could not set the case up"}
+    try:
+        if transport == "rccl":
+            # a communicator of its own: the first one went with the weak-scaling context
+            import torch.distributed as dist
+            ident = [capi.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            sim.use_rccl(ident[0])
+        else:
+            host_tr = HostTransport(rank, world)
+            sim.set_transport(host_tr.struct)
+            sim._strong_transport = host_tr  # keep the callbacks alive
+    except Exception as e:
+        err = repr(e)
+    if all_ok_soft(err):
+        sim.close()
+        return {"error": err or "another rank could not open its transport"}
+    sim.forces(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    done = 0
+    while done < args.preroll:
+        m = min(20, args.preroll - done)
+        sim.step(m)
+        done += m
+    for _ in range(args.warmup):
+        sim.step(1)
+    legs = B.Legs(sim, args, sync, agree_max)
+    k = max(1, args.strong_steps)
+    dev = legs.timed(k)
+    n = sim.npts_global
+    per = agree_max([float(sim.npts)])[0]
+    sim.close()
+    value = n * k / dev["elapsed"]
+    anchor, where = single_gpu_anchor(fluid)
+    return {
+        "what": "fluid %dx%dx%d cut into %d x-slabs, %d steps advanced untimed, then %d timed steps (developed flow)"
+                % (fluid[0], fluid[1], fluid[2], world, args.preroll, k),
+        "particles": n, "most_particles_on_a_rank": int(per), "value": value, "unit": "particle-steps/s",
+        "ms_per_step": dev["ms_per_step"], "pair_ms": dev["pair_ms"], "list_rebuilds": dev["rebuilds"],
+        "rebuild_ms_each": dev["rebuild_ms_each"], "exchange": dev["comm"],
+        "single_gpu_value": anchor, "single_gpu_source": where,
+        "efficiency": (value / (world * anchor)) if anchor else None,
+    }
