@@ -209,6 +209,11 @@ typedef struct sph_transport {
     /* 1: buffers handed to the callbacks are host memory (the library stages them); 0: device
      * memory, and `stream` (a hipStream_t) orders the transfer. */
     int32_t host_buffers;
+    /* sizeof(sph_transport) as the caller was compiled: zero the struct, set this, then the rest.
+     * sph_set_transport refuses any other value, so a caller built against a header with fewer
+     * callbacks (or one that left the struct uninitialised) is told so instead of having a
+     * callback it never set called. */
+    uint32_t struct_size;
     /* Send `nsendL` bytes to the left neighbour (rank-1) and `nsendR` to the right (rank+1);
      * receive exactly `nrecvL` / `nrecvR` bytes from them.  A side without a neighbour has
      * byte counts 0.  Returns 0 on success. */
@@ -221,7 +226,8 @@ typedef struct sph_transport {
     int (*allreduce_max_sum)(void* user, double* maxvals, int32_t nmax, double* sumvals, int32_t nsum, void* stream);
 } sph_transport;
 
-/* Installs the transport (copied).  Required before the first Forces/step when nranks > 1. */
+/* Installs the transport (copied).  Required before the first Forces/step when nranks > 1.
+ * SPH_EINVAL when struct_size is not sizeof(sph_transport) or a required callback is NULL. */
 int sph_set_transport(sph_ctx* ctx, const sph_transport* t);
 /* Global original indices of this rank's particles, in upload order (wall particles are the
  * ones below bound_parts of the GLOBAL numbering).  Required when nranks > 1. */

@@ -77,8 +77,20 @@ ALLREDUCE2_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int3
 
 
 class Transport(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("host_buffers", C.c_int32), ("sendrecv", SENDRECV_FN),
-                ("allreduce", ALLREDUCE_FN), ("allreduce_max_sum", ALLREDUCE2_FN)]
+    _fields_ = [("user", C.c_void_p), ("host_buffers", C.c_int32), ("struct_size", C.c_uint32),
+                ("sendrecv", SENDRECV_FN), ("allreduce", ALLREDUCE_FN), ("allreduce_max_sum", ALLREDUCE2_FN)]
+
+
+def make_transport(host_buffers, sendrecv, allreduce, allreduce_max_sum=None):
+    """A zeroed sph_transport with its size and the callbacks filled in."""
+    t = Transport()
+    t.host_buffers = host_buffers
+    t.struct_size = C.sizeof(Transport)
+    t.sendrecv = sendrecv
+    t.allreduce = allreduce
+    if allreduce_max_sum is not None:
+        t.allreduce_max_sum = allreduce_max_sum
+    return t
 
 
 class SphError(RuntimeError):

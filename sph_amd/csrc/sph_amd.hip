@@ -132,6 +132,8 @@ struct sph_ctx {
     ReinitCtl* ri_ctl = nullptr;
     uint32_t* ri_flow = nullptr; /* control words of the one-launch walk */
     uint32_t ri_owners = 0;      /* its workgroups (all resident at once); 0 = walk by levels */
+    bool lost = false;           /* a launch of this context never came back: every later call fails at once, and
+                                    sph_destroy frees nothing on the device (it would wait for that launch) */
     uint32_t ri_gen = 0;         /* its calls so far: the tag of the densities a call publishes */
     double ri_limit_s = 10.0;    /* a wave of it gives up after waiting this long for one thing (a whole walk takes < 1 s) */
     uint64_t reinit_launches = 0;
@@ -1573,6 +1575,10 @@ int sph_create(const sph_params* p, sph_ctx** out) {
 
 void sph_destroy(sph_ctx* c) {
     if (!c) return;
+    if (c->lost) { /* anything that waits for the stream would wait for ever */
+        delete c;
+        return;
+    }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)hipStreamSynchronize(c->comm);
     if (c->rccl && c->rccl_free) c->rccl_free(c->rccl);
@@ -1616,7 +1622,11 @@ void sph_destroy(sph_ctx* c) {
 }
 
 int sph_set_transport(sph_ctx* c, const sph_transport* t) {
-    if (!c || !t || !t->sendrecv || !t->allreduce) return SPH_EINVAL;
+    if (!c || !t) return SPH_EINVAL;
+    if (t->struct_size != sizeof(sph_transport))
+        return fail(c, SPH_EINVAL, "sph_transport.struct_size is not sizeof(sph_transport): zero the struct, set struct_size, "
+                                   "then the callbacks (a caller built against another version of the header?)");
+    if (!t->sendrecv || !t->allreduce) return fail(c, SPH_EINVAL, "sph_transport: sendrecv and allreduce are required");
     if (!c->dist) return fail(c, SPH_ESTATE, "a transport is only used when nranks > 1");
     c->tr = *t;
     c->have_tr = true;
@@ -1666,6 +1676,7 @@ int sph_download_global_ids(sph_ctx* c, uint32_t* gids) {
 }
 
 int sph_upload(sph_ctx* c, int32_t which, const sph_fields* s) {
+    if (c && c->lost) return fail(c, SPH_ESTATE, "the context is lost (an earlier call reported a launch that never came back)");
     if (!c || !s) return SPH_EINVAL;
     if (which != SPH_STATE_N && which != SPH_STATE_NP1) return fail(c, SPH_EINVAL, "bad state selector");
     HIPCHK(hipSetDevice(c->device));
@@ -1706,6 +1717,7 @@ int sph_upload(sph_ctx* c, int32_t which, const sph_fields* s) {
 }
 
 int sph_download(sph_ctx* c, int32_t which, const sph_fields* s) {
+    if (c && c->lost) return fail(c, SPH_ESTATE, "the context is lost (an earlier call reported a launch that never came back)");
     if (!c || !s) return SPH_EINVAL;
     if (which != SPH_STATE_N && which != SPH_STATE_NP1) return fail(c, SPH_EINVAL, "bad state selector");
     HIPCHK(hipSetDevice(c->device));
@@ -1738,6 +1750,7 @@ int sph_download(sph_ctx* c, int32_t which, const sph_fields* s) {
 }
 
 int sph_forces(sph_ctx* c, int32_t which) {
+    if (c && c->lost) return fail(c, SPH_ESTATE, "the context is lost (an earlier call reported a launch that never came back)");
     if (!c) return SPH_EINVAL;
     if (which != SPH_STATE_N && which != SPH_STATE_NP1) return fail(c, SPH_EINVAL, "bad state selector");
     if (which == SPH_STATE_N ? !c->uploaded_n : !c->uploaded_np1) return fail(c, SPH_ESTATE, "state was never uploaded");
@@ -1768,6 +1781,7 @@ int sph_forces(sph_ctx* c, int32_t which) {
 }
 
 int sph_zero_boundary_forces(sph_ctx* c, int32_t which) {
+    if (c && c->lost) return fail(c, SPH_ESTATE, "the context is lost (an earlier call reported a launch that never came back)");
     if (!c) return SPH_EINVAL;
     if (which != SPH_STATE_N && which != SPH_STATE_NP1) return fail(c, SPH_EINVAL, "bad state selector");
     HIPCHK(hipSetDevice(c->device));
@@ -1780,6 +1794,7 @@ int sph_zero_boundary_forces(sph_ctx* c, int32_t which) {
 }
 
 int sph_step(sph_ctx* c, int32_t nsteps, sph_scalars* out) {
+    if (c && c->lost) return fail(c, SPH_ESTATE, "the context is lost (an earlier call reported a launch that never came back)");
     if (!c || nsteps < 0) return SPH_EINVAL;
     if (!c->uploaded_n || !c->uploaded_np1) return fail(c, SPH_ESTATE, "both states must be uploaded before stepping");
     HIPCHK(hipSetDevice(c->device));
@@ -1790,6 +1805,7 @@ int sph_step(sph_ctx* c, int32_t nsteps, sph_scalars* out) {
 }
 
 int sph_step_noalloc(sph_ctx* c, int32_t nsteps, sph_scalars* out) {
+    if (c && c->lost) return fail(c, SPH_ESTATE, "the context is lost (an earlier call reported a launch that never came back)");
     if (!c || nsteps < 0) return SPH_EINVAL;
     if (!c->uploaded_n || !c->uploaded_np1) return fail(c, SPH_ESTATE, "both states must be uploaded before stepping");
     if (c->dist) return fail(c, SPH_EINVAL, "sph_step_noalloc serves single-domain contexts only");
@@ -1813,6 +1829,7 @@ int sph_step_noalloc(sph_ctx* c, int32_t nsteps, sph_scalars* out) {
 }
 
 int sph_sweeps(sph_ctx* c, int32_t nsweeps, sph_scalars* out) {
+    if (c && c->lost) return fail(c, SPH_ESTATE, "the context is lost (an earlier call reported a launch that never came back)");
     if (!c || nsweeps < 1 || nsweeps > c->prm.subits) return SPH_EINVAL;
     if (!c->uploaded_n || !c->uploaded_np1) return fail(c, SPH_ESTATE, "both states must be uploaded before stepping");
     HIPCHK(hipSetDevice(c->device));
@@ -1822,6 +1839,7 @@ int sph_sweeps(sph_ctx* c, int32_t nsweeps, sph_scalars* out) {
 }
 
 int sph_get_scalars(sph_ctx* c, sph_scalars* out) {
+    if (c && c->lost) return fail(c, SPH_ESTATE, "the context is lost (an earlier call reported a launch that never came back)");
     if (!c || !out) return SPH_EINVAL;
     HIPCHK(hipSetDevice(c->device));
     CHK(read_scalars(c));
@@ -1830,6 +1848,7 @@ int sph_get_scalars(sph_ctx* c, sph_scalars* out) {
 }
 
 int sph_set_dt(sph_ctx* c, double dt) {
+    if (c && c->lost) return fail(c, SPH_ESTATE, "the context is lost (an earlier call reported a launch that never came back)");
     if (!c || !(dt > 0)) return SPH_EINVAL;
     HIPCHK(hipSetDevice(c->device));
     const double v[2] = {dt, dt};
@@ -1981,8 +2000,12 @@ int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
                     raised = true;
                     fprintf(stderr, "[sph] density re-initialisation: stop flag raised by the host after %.1f s\n", waited);
                 }
-                if (waited > 4.0 * c->ri_limit_s + 20.0)
-                    return fail(c, SPH_ESTATE, "density re-initialisation does not come back; the context is lost");
+                if (waited > 4.0 * c->ri_limit_s + 20.0) {
+                    c->lost = true;
+                    c->ri_owners = 0;
+                    return fail(c, SPH_ESTATE, "density re-initialisation does not come back; the context is lost "
+                                               "(its stream still holds the launch: end the process with a failure code)");
+                }
                 if (waited > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(200));
             }
         }
@@ -2014,6 +2037,7 @@ int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
 }  // namespace
 
 int sph_density_reinit(sph_ctx* c) {
+    if (c && c->lost) return fail(c, SPH_ESTATE, "the context is lost (an earlier call reported a launch that never came back)");
     if (!c) return SPH_EINVAL;
     if (!c->uploaded_np1) return fail(c, SPH_ESTATE, "state was never uploaded");
     HIPCHK(hipSetDevice(c->device));
@@ -2068,6 +2092,7 @@ int sph_density_reinit(sph_ctx* c) {
 }
 
 int sph_neighbours(sph_ctx* c, int32_t which, uint64_t* row_offsets, uint32_t* cols) {
+    if (c && c->lost) return fail(c, SPH_ESTATE, "the context is lost (an earlier call reported a launch that never came back)");
     if (!c || !row_offsets) return SPH_EINVAL;
     if (which != SPH_STATE_N && which != SPH_STATE_NP1) return fail(c, SPH_EINVAL, "bad state selector");
     if (which == SPH_STATE_N ? !c->uploaded_n : !c->uploaded_np1) return fail(c, SPH_ESTATE, "state was never uploaded");
@@ -2394,6 +2419,8 @@ int sph_use_rccl(sph_ctx* c, const void* unique_id_128) {
     c->rccl = r;
     c->rccl_free = rccl_release;
     sph_transport t;
+    memset(&t, 0, sizeof t);
+    t.struct_size = sizeof t;
     t.user = r;
     t.host_buffers = 0;
     t.sendrecv = rccl_sendrecv;

@@ -68,7 +68,7 @@ class HostTransport:
         self.exchanges = 0  # sendrecv calls so far
         self._sr = capi.SENDRECV_FN(self._sendrecv)
         self._ar = capi.ALLREDUCE_FN(self._allreduce)
-        self.struct = capi.Transport(None, 1, self._sr, self._ar)
+        self.struct = capi.make_transport(1, self._sr, self._ar)
 
     def _sendrecv(self, user, sL, nsL, rL, nrL, sR, nsR, rR, nrR, stream):
         try:
@@ -115,7 +115,7 @@ class DeviceTransport(HostTransport):
         self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self._sr_dev = capi.SENDRECV_FN(self._sendrecv_dev)
         self._ar_dev = capi.ALLREDUCE_FN(self._allreduce_dev)
-        self.struct = capi.Transport(None, 0, self._sr_dev, self._ar_dev)
+        self.struct = capi.make_transport(0, self._sr_dev, self._ar_dev)
 
     def _to_host(self, dptr, n):
         buf = (C.c_ubyte * max(n, 1))()

@@ -303,11 +303,17 @@ void pack_rows(const HostState& s, const std::vector<uint32_t>& gids, std::vecto
     put(s.rho.data(), n * 4);
     put(s.p.data(), n * 4);
 }
-void unpack_rows(const char* p, int dim, HostState& whole) {
+/* false when the message is not what pack_rows makes for a whole of `whole.n` rows: its length
+ * does not follow from its count, or an index names no row */
+bool unpack_rows(const char* p, size_t bytes, int dim, HostState& whole) {
+    if (bytes < 8) return false;
     uint64_t n;
     memcpy(&n, p, 8);
+    if (n > whole.n || bytes != 8 + n * 4 + n * 8 * (uint64_t)(3 * dim) + n * 4 * 2) return false;
     p += 8;
     const uint32_t* g = (const uint32_t*)p;
+    for (uint64_t i = 0; i < n; ++i)
+        if (g[i] >= whole.n) return false;
     p += n * 4;
     for (int d = 0; d < dim; ++d) {
         std::vector<double>* dst[3] = {&whole.x[d], &whole.v[d], &whole.f[d]};
@@ -322,10 +328,16 @@ void unpack_rows(const char* p, int dim, HostState& whole) {
     p += n * 4;
     const float* pr = (const float*)p;
     for (uint64_t i = 0; i < n; ++i) whole.p[g[i]] = pr[i];
+    return true;
 }
+
+/* the sockets of this process, for die(): a rank that gives up closes them, so that the others
+ * fail in their next exchange instead of waiting for it */
+Wire* g_wire = nullptr;
 
 void die(sph_ctx* ctx, const char* what) {
     std::cerr << what << ": " << sph_last_error(ctx) << std::endl;
+    if (g_wire) g_wire->shutdown_all();
     exit(-1);
 }
 
@@ -374,6 +386,7 @@ int main(int argc, char* argv[]) {
     const int rank = env_int(k_rank, 0), nranks = std::max(1, env_int(k_size, 1)), local_rank = env_int(k_local, 0);
     const bool root = rank == 0, multi = nranks > 1;
     Wire wire;
+    g_wire = &wire;
     if (multi) {
         static const char* const k_port[] = {"SPH_WIRE_PORT", nullptr};
         static const char* const k_mport[] = {"MASTER_PORT", nullptr};
@@ -384,6 +397,9 @@ int main(int argc, char* argv[]) {
             std::cerr << "rank " << rank << ": " << wire.error << std::endl;
             exit(-1);
         }
+        /* nothing a rank sends is larger than all the particles' full records (240 bytes each
+         * when they migrate, 84 in a frame's rows) */
+        wire.max_message = 4096 + npts_all * 256;
     }
     prm.device = st.device >= 0 ? st.device : (multi ? local_rank : -1);
 
@@ -448,6 +464,7 @@ int main(int argc, char* argv[]) {
             if (sph_use_rccl(ctx, id) != SPH_OK) die(ctx, "sph_use_rccl");
         } else {
             memset(&wire_tr, 0, sizeof wire_tr);
+            wire_tr.struct_size = sizeof wire_tr;
             wire_tr.user = &wire;
             wire_tr.host_buffers = 1;
             wire_tr.sendrecv = wire_sendrecv;
@@ -486,8 +503,13 @@ int main(int argc, char* argv[]) {
         std::vector<std::vector<char> > all;
         if (!wire.gather(mine.data(), mine.size(), &all)) { std::cerr << wire.error << std::endl; exit(-1); }
         if (root) {
-            unpack_rows(mine.data(), prm.dim, *dst);
-            for (int k = 1; k < nranks; ++k) unpack_rows(all[(size_t)k].data(), prm.dim, *dst);
+            bool good = unpack_rows(mine.data(), mine.size(), prm.dim, *dst);
+            for (int k = 1; k < nranks && good; ++k) good = unpack_rows(all[(size_t)k].data(), all[(size_t)k].size(), prm.dim, *dst);
+            if (!good) {
+                std::cerr << "a rank's frame rows do not fit the run (length or index out of range)" << std::endl;
+                wire.shutdown_all();
+                exit(-1);
+            }
         }
     };
 

@@ -33,6 +33,27 @@ class Wire {
 public:
     int rank = 0, size = 1;
     std::string error;
+    /* No message of a run is larger than this (the driver sets it from the capacity of its
+     * context): a length beyond it read from a peer ends the exchange instead of sizing a buffer. */
+    uint64_t max_message = 1ull << 32;
+    /* seconds a receive may wait for its peer before the exchange fails (a rank that died or
+     * never started must not leave the others blocked for ever) */
+    int recv_timeout_s = 600;
+
+    /* closes every connection: peers blocked in an exchange with this rank then fail instead of
+     * waiting (called by the driver before it exits on an error) */
+    void shutdown_all() {
+        for (int& fd : fds_)
+            if (fd >= 0) {
+                ::shutdown(fd, SHUT_RDWR);
+                close(fd);
+                fd = -1;
+            }
+        if (listen_fd_ >= 0) {
+            close(listen_fd_);
+            listen_fd_ = -1;
+        }
+    }
 
     ~Wire() {
         for (int fd : fds_)
@@ -40,35 +61,13 @@ public:
         if (listen_fd_ >= 0) close(listen_fd_);
     }
 
-    /* rank 0 listens on addr:port and accepts size-1 peers; the others connect (retrying while
-     * rank 0 is not up yet) and say who they are */
+    /* rank 0 listens on addr:port (the address the ranks were given: loopback unless the launcher
+     * names another) and accepts size-1 peers within timeout_s; the others connect (retrying
+     * while rank 0 is not up yet) and say who they are */
     bool open(int rank_, int size_, const std::string& addr, int port, int timeout_s = 120) {
         rank = rank_;
         size = size_;
         if (size <= 1) return true;
-        if (rank == 0) {
-            listen_fd_ = socket(AF_INET, SOCK_STREAM, 0);
-            if (listen_fd_ < 0) return fail("socket");
-            int one = 1;
-            setsockopt(listen_fd_, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-            sockaddr_in sa;
-            memset(&sa, 0, sizeof sa);
-            sa.sin_family = AF_INET;
-            sa.sin_addr.s_addr = htonl(INADDR_ANY);
-            sa.sin_port = htons((uint16_t)port);
-            if (bind(listen_fd_, (sockaddr*)&sa, sizeof sa) != 0) return fail("bind");
-            if (listen(listen_fd_, size) != 0) return fail("listen");
-            fds_.assign((size_t)size, -1);
-            for (int k = 1; k < size; ++k) {
-                const int fd = accept(listen_fd_, nullptr, nullptr);
-                if (fd < 0) return fail("accept");
-                setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-                int32_t who = -1;
-                if (!recv_all(fd, &who, sizeof who) || who < 1 || who >= size || fds_[(size_t)who] >= 0) return fail("bad peer");
-                fds_[(size_t)who] = fd;
-            }
-            return true;
-        }
         addrinfo hints, *res = nullptr;
         memset(&hints, 0, sizeof hints);
         hints.ai_family = AF_INET;
@@ -76,6 +75,38 @@ public:
         const std::string ps = std::to_string(port);
         if (getaddrinfo(addr.c_str(), ps.c_str(), &hints, &res) != 0 || !res) return fail("getaddrinfo");
         const auto t0 = std::chrono::steady_clock::now();
+        if (rank == 0) {
+            listen_fd_ = socket(AF_INET, SOCK_STREAM, 0);
+            if (listen_fd_ < 0) { freeaddrinfo(res); return fail("socket"); }
+            int one = 1;
+            setsockopt(listen_fd_, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+            const int bound = bind(listen_fd_, res->ai_addr, res->ai_addrlen);
+            freeaddrinfo(res);
+            if (bound != 0) return fail("bind");
+            if (listen(listen_fd_, size) != 0) return fail("listen");
+            fds_.assign((size_t)size, -1);
+            for (int k = 1; k < size; ++k) {
+                /* a peer that never starts must not hold rank 0 for ever */
+                const long left = timeout_s - (long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count();
+                timeval tv;
+                tv.tv_sec = left > 1 ? left : 1;
+                tv.tv_usec = 0;
+                setsockopt(listen_fd_, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+                const int fd = accept(listen_fd_, nullptr, nullptr);
+                if (fd < 0) return fail("accept (a rank did not connect in time)");
+                setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+                set_timeouts(fd);
+                int32_t who = -1;
+                if (!recv_all(fd, &who, sizeof who) || who < 1 || who >= size || fds_[(size_t)who] >= 0) {
+                    /* not one of this run's ranks: drop it and keep waiting for them */
+                    close(fd);
+                    --k;
+                    continue;
+                }
+                fds_[(size_t)who] = fd;
+            }
+            return true;
+        }
         int fd = -1;
         for (;;) {
             fd = socket(AF_INET, SOCK_STREAM, 0);
@@ -90,6 +121,7 @@ public:
         if (fd < 0) return fail("connect to rank 0");
         int one = 1;
         setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        set_timeouts(fd);
         const int32_t who = rank;
         if (!send_all(fd, &who, sizeof who)) return fail("hello");
         fds_.assign(1, fd);
@@ -139,6 +171,7 @@ public:
         for (int k = 1; k < size; ++k) {
             uint64_t head[2];
             if (!recv_all(fds_[(size_t)k], head, sizeof head)) return fail("sendrecv head");
+            if (head[0] > max_message || head[1] > max_message) return fail("sendrecv: a peer names a length beyond any message of this run");
             toL[(size_t)k].resize(head[0]);
             toR[(size_t)k].resize(head[1]);
             if (!recv_all(fds_[(size_t)k], toL[(size_t)k].data(), head[0]) || !recv_all(fds_[(size_t)k], toR[(size_t)k].data(), head[1]))
@@ -169,6 +202,7 @@ public:
         for (int k = 1; k < size; ++k) {
             uint64_t m = 0;
             if (!recv_all(fds_[(size_t)k], &m, sizeof m)) return fail("gather head");
+            if (m > max_message) return fail("gather: a peer names a length beyond any message of this run");
             (*all)[(size_t)k].resize(m);
             if (!recv_all(fds_[(size_t)k], (*all)[(size_t)k].data(), m)) return fail("gather body");
         }
@@ -178,6 +212,14 @@ public:
 private:
     std::vector<int> fds_;
     int listen_fd_ = -1;
+
+    void set_timeouts(int fd) const {
+        timeval tv;
+        tv.tv_sec = recv_timeout_s;
+        tv.tv_usec = 0;
+        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+    }
 
     bool fail(const char* what) {
         error = std::string("wire: ") + what + (errno ? std::string(": ") + strerror(errno) : std::string());

@@ -37,6 +37,10 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(capi.Fields) == 8 * 16
     assert C.sizeof(capi.Scalars) == 8 + 8 + 8 * 4 + 8 * 4
     assert C.sizeof(capi.Case) == 16 + 8 + 24 + 24 + 8 + 32 + 8 + 8 + 24 + 8 + 24
+    # sph_transport: user, host_buffers + struct_size in one 8-byte slot, three callbacks
+    assert C.sizeof(capi.Transport) == 8 + 8 + 3 * 8
+    assert capi.Transport.struct_size.offset == 12 and capi.Transport.sendrecv.offset == 16
+    assert capi.make_transport(1, capi.SENDRECV_FN(), capi.ALLREDUCE_FN()).struct_size == 40
 
 
 @pytest.mark.parametrize("program", [0, 1, 2])

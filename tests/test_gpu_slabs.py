@@ -288,7 +288,7 @@ def test_device_buffer_transport(name, nranks, vx, tmp_path):
     # over device buffers the step's agreement (one exchange of maxima and sums) stays on the
     # device: the host waits once per step, redone steps aside (list rebuilds are not counted)
     syncs, steps = res["host_syncs_in_steps"]
-    assert syncs <= 2 * (steps + res["scalars"][7]), (syncs, steps)
+    assert syncs == steps + res["scalars"][7], (syncs, steps, res["scalars"][7])
 
 
 # ---- DensityReinit across slabs ----------------------------------------------------------------
