@@ -18,6 +18,8 @@ def classify(op):
         return "cross-lane move (DPP)"
     if op.startswith("v_"):
         return "other vector ALU"
+    if op.startswith("global_load_lds"):
+        return "VMEM global->LDS copy"
     if op.startswith("global_load"):
         return "VMEM load"
     if op.startswith("global_store") or op.startswith("global_atomic"):
@@ -47,11 +49,12 @@ body = text[start:end + 1]
 print("k_pair<3, xsph, fused, 32-bit offsets>: %d lines of assembly" % len(body))
 for k, v in sorted(census(body).items(), key=lambda kv: -kv[1]):
     print("  whole kernel  %-36s %5d" % (k, v))
-# one round: from the first ds_write_b128 group inside the loop to the next loop-body label after the arithmetic
-w = [i for i, l in enumerate(body) if "ds_write_b128" in l]
-first = w[0]
-nxt = next(i for i in w if i > first + 8)  # the next round's exchange
-rnd = body[first:nxt]
-print("one round of the pair loop (%d lines):" % len(rnd))
-for k, v in sorted(census(rnd).items(), key=lambda kv: -kv[1]):
-    print("  per round     %-36s %5d" % (k, v))
+# one round: from the first of a round's four global->LDS copies to the first of the next round's
+# (the rounds of a super-round are unrolled; the second and third copy groups bracket a plain round)
+copies = [i for i, l in enumerate(body) if "global_load_lds_dwordx4" in l]
+groups = [i for k, i in enumerate(copies) if k == 0 or i - copies[k - 1] > 8]
+if len(groups) >= 3:
+    rnd = body[groups[1]:groups[2]]
+    print("one round of the pair loop (%d lines):" % len(rnd))
+    for k, v in sorted(census(rnd).items(), key=lambda kv: -kv[1]):
+        print("  per round     %-36s %5d" % (k, v))
