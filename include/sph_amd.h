@@ -197,6 +197,18 @@ int sph_profile_read_kinds(sph_ctx* ctx, double* ms3, uint64_t* launches3);
  * slab, both host time (they wait for the device).  Sums in ms and counts. */
 int sph_profile_read_comm(sph_ctx* ctx, double* ms4, uint64_t* count4);
 
+/* How the last sph_density_reinit went through the particles (no counterpart in the reference,
+ * whose DensityReinit is one loop in index order, WCXSPH3D.cpp:205-252; every way below gives that
+ * loop's values): [0] one of SPH_REINIT_*, [1] launches of the walk's kernels, [2] slab runs: the
+ * rounds of exchanges with the neighbouring ranks, [3] 1 when the ranks walked one after the other
+ * because they share a GPU.  The array has four entries. */
+#define SPH_REINIT_NONE 0
+#define SPH_REINIT_ONE_WORKGROUP 1      /* small cases: one workgroup, a barrier per dependency level */
+#define SPH_REINIT_LEVELS 2             /* one launch per dependency level */
+#define SPH_REINIT_ONE_LAUNCH 3         /* one launch, a queue per workgroup */
+#define SPH_REINIT_ONE_LAUNCH_ROUNDS 4  /* slab runs: that launch once per round of exchanges */
+int sph_reinit_info(sph_ctx* ctx, uint64_t* out4);
+
 /* ---- slab decomposition ----------------------------------------------------------------
  * No counterpart in the reference.  A rank owns the particles whose x lay in its interval at
  * upload.  Before every Forces call each rank needs, from each slab neighbour, the records of

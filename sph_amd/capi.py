@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("SPH_AMD_LIB") or os.path.join(_HERE, "lib", "libsph_a
 OK, EINVAL, EDEVICE, ENOMEM, ESTATE, ECOMM = range(6)
 VARIANT_WCSPH, VARIANT_WCXSPH = 0, 1
 STATE_N, STATE_NP1 = 0, 1
+REINIT_NONE, REINIT_ONE_WORKGROUP, REINIT_LEVELS, REINIT_ONE_LAUNCH, REINIT_ONE_LAUNCH_ROUNDS = range(5)
 PROGRAM_WCSPH, PROGRAM_WCXSPH, PROGRAM_WCXSPH3D = 0, 1, 2
 
 # every symbol include/sph_amd.h declares
@@ -24,7 +25,7 @@ SYMBOLS = (
     "sph_create", "sph_destroy", "sph_last_error", "sph_upload", "sph_download", "sph_forces",
     "sph_zero_boundary_forces", "sph_step", "sph_step_noalloc", "sph_sweeps", "sph_get_scalars", "sph_set_dt",
     "sph_density_reinit", "sph_neighbours", "sph_profile_enable", "sph_profile_read", "sph_profile_read_kinds",
-    "sph_profile_read_comm",
+    "sph_profile_read_comm", "sph_reinit_info",
     "sph_case_default", "sph_case_params", "sph_case_init",
     "sph_set_transport", "sph_upload_global_ids", "sph_rccl_unique_id", "sph_use_rccl",
     "sph_case_init_range", "sph_case_histogram_x", "sph_local_count", "sph_download_global_ids",
@@ -134,6 +135,7 @@ def lib():
     L.sph_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sph_profile_read_kinds.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.sph_reinit_info.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.sph_profile_read_comm.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sph_case_default.argtypes = [C.c_int32, C.POINTER(Case)]
     L.sph_case_params.argtypes = [C.POINTER(Case), C.POINTER(Params), C.POINTER(C.c_double),
@@ -406,6 +408,12 @@ class Sim:
 
     def density_reinit(self):
         self._chk(lib().sph_density_reinit(self._h), "sph_density_reinit")
+
+    def reinit_info(self):
+        """How the last density_reinit() walked: dict(walk=one of REINIT_*, launches, rounds, took_turns)."""
+        out = (C.c_uint64 * 4)()
+        self._chk(lib().sph_reinit_info(self._h, out), "sph_reinit_info")
+        return dict(walk=int(out[0]), launches=int(out[1]), rounds=int(out[2]), took_turns=bool(out[3]))
 
     def neighbours(self, which):
         offs = np.zeros(self.npts + 1, np.uint64)

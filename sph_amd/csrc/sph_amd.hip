@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unistd.h>
 #include <vector>
 
 #include "sph_kernels.h"
@@ -132,12 +133,15 @@ struct sph_ctx {
     ReinitCtl* ri_ctl = nullptr;
     uint32_t* ri_flow = nullptr; /* control words of the one-launch walk */
     uint32_t ri_owners = 0;      /* its workgroups (all resident at once); 0 = walk by levels */
+    size_t ri_gran_off = 0;      /* where the one-launch walk's published words began at the last call */
+    bool ri_take_turns = false;  /* slab run, ranks sharing a GPU: the one-launch walks run one rank at a time */
     bool lost = false;           /* a launch of this context never came back: every later call fails at once, and
                                     sph_destroy frees nothing on the device (it would wait for that launch) */
     uint32_t ri_gen = 0;         /* its calls so far: the tag of the densities a call publishes */
     double ri_limit_s = 10.0;    /* a wave of it gives up after waiting this long for one thing (a whole walk takes < 1 s) */
-    uint64_t reinit_launches = 0;
-    uint64_t reinit_rounds = 0; /* slab runs: exchanges of the last density re-initialisation */
+    uint64_t reinit_launches = 0; /* of the last density re-initialisation: launches of its walk, */
+    uint64_t reinit_rounds = 0;   /* exchange rounds (slab runs) */
+    uint32_t reinit_walked = 0;   /* and how it walked (SPH_REINIT_*) */
 
     uint64_t rebuilds = 0, redos = 0;
     uint64_t host_syncs = 0; /* host waits for the device on the stepping path outside list rebuilds */
@@ -1859,6 +1863,54 @@ int sph_set_dt(sph_ctx* c, double dt) {
 
 namespace {
 
+/* One launch of the one-launch walk (or one round of it, in a slab run) and the wait for it.  The
+ * waves give up by themselves after the context's time limit; should the launch outlive that by
+ * far, the host raises the stop flag from a second stream, and if even that does not end it the
+ * context is lost.  *stop_word: the stop flag as the launch left it (0, REINIT_STOP_GAVE_UP,
+ * REINIT_STOP_DRY). */
+int reinit_flow_launch(sph_ctx* c, Rec* r, const uint32_t* ids, uint32_t owners, uint32_t qseg, unsigned long long* gran,
+                       int partial, uint32_t* stop_word) {
+    const uint64_t limit = (uint64_t)(c->ri_limit_s * 1e8); /* ticks of the 100 MHz clock */
+    uint32_t* const h = (uint32_t*)c->need_host; /* pinned */
+    if (c->dim == 3)
+        hipLaunchKernelGGL(k_reinit_flow<3>, dim3(owners), dim3(REINIT_FLOW_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
+                           c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, qseg, limit, gran, c->ri_gen, partial);
+    else
+        hipLaunchKernelGGL(k_reinit_flow<2>, dim3(owners), dim3(REINIT_FLOW_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
+                           c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, qseg, limit, gran, c->ri_gen, partial);
+    HIPCHK(hipGetLastError());
+    ++c->reinit_launches;
+    HIPCHK(hipMemcpyAsync(h, c->ri_flow, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    const auto t_start = std::chrono::steady_clock::now();
+    bool raised = false;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIPCHK(q);
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        if (!raised && waited > 2.0 * c->ri_limit_s + 5.0) {
+            hipStream_t side;
+            HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            static const uint32_t one = REINIT_STOP_GAVE_UP;
+            HIPCHK(hipMemcpyAsync(c->ri_flow, &one, sizeof one, hipMemcpyHostToDevice, side));
+            HIPCHK(hipStreamSynchronize(side));
+            HIPCHK(hipStreamDestroy(side));
+            raised = true;
+            fprintf(stderr, "[sph] density re-initialisation: stop flag raised by the host after %.1f s\n", waited);
+        }
+        if (waited > 4.0 * c->ri_limit_s + 20.0) {
+            c->lost = true;
+            c->ri_owners = 0;
+            return fail(c, SPH_ESTATE, "density re-initialisation does not come back; the context is lost "
+                                       "(its stream still holds the launch: end the process with a failure code)");
+        }
+        if (waited > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *stop_word = *h;
+    return SPH_OK;
+}
+
 /* The walk of DensityReinit over lists that are already built; `one_launch` picks the one-launch
  * walk (a single rank's large case).  *stalled: that walk gave up with all its waves gone. */
 int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
@@ -1882,9 +1934,16 @@ int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
     const uint32_t owners = one_launch ? c->ri_owners : 0u;
     const uint32_t qseg = owners ? (n + owners - 1) / owners + 1u : 0u;
     if (owners) {
-        if ((size_t)owners * qseg + 2 + 2 * (size_t)n > (size_t)3 * c->cap + 1024)
+        if ((size_t)owners * qseg + 2 + 2 * ((size_t)n + c->n_halo) > (size_t)3 * c->cap + 1024)
             return fail(c, SPH_ESTATE, "density re-initialisation: queues do not fit");
         ++c->ri_gen;
+        /* the published words sit behind the queues; when the particle count has changed (a slab
+         * run's migration) they lie where queue entries were, which could pass for tags */
+        const size_t gran_off = ((size_t)owners * qseg + 1) & ~(size_t)1;
+        if (gran_off != c->ri_gran_off) {
+            HIPCHK(hipMemsetAsync(c->ri_queue + gran_off, 0, sizeof(uint32_t) * ((size_t)3 * c->cap + 1024 - gran_off), c->stream));
+            c->ri_gran_off = gran_off;
+        }
         HIPCHK(hipMemsetAsync(c->ri_queue, 0xFF, sizeof(uint32_t) * (size_t)owners * qseg, c->stream));
         HIPCHK(hipMemsetAsync(c->ri_flow, 0, sizeof(uint32_t) * REINIT_FLOW_WORDS(owners), c->stream));
     }
@@ -1896,7 +1955,89 @@ int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
                            ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches, owners, qseg, c->ri_flow);
     HIPCHK(hipGetLastError());
     ReinitCtl* h = (ReinitCtl*)c->need_host; /* pinned, 8 words */
-    if (c->dist) {
+    c->reinit_walked = c->dist ? (owners ? SPH_REINIT_ONE_LAUNCH_ROUNDS : SPH_REINIT_LEVELS)
+                               : (n <= REINIT_SINGLE_MAX ? SPH_REINIT_ONE_WORKGROUP : owners ? SPH_REINIT_ONE_LAUNCH : SPH_REINIT_LEVELS);
+    if (c->dist && owners) {
+        /* Slab run, one-launch walk in rounds.  The walk is in global index order, so a particle
+         * may wait for one of a neighbouring rank: it is then not released.  A round: every rank
+         * walks until its walk has run dry (k_reinit_flow, partial); the ranks tell their
+         * neighbours the new rho of the shared particles that are finished; each publishes what it
+         * is told, recounts the waiting particles next to those and queues the ones set free.
+         * Same values as the walk over the whole domain. */
+        unsigned long long* const gran = (unsigned long long*)(c->ri_queue + (((size_t)owners * qseg + 1) & ~(size_t)1));
+        const size_t hc = c->halo_cap;
+        std::vector<uint32_t> words(REINIT_FLOW_WORDS(owners));
+        auto read_counts = [&](uint64_t* pushed, uint64_t* finished) -> int {
+            HIPCHK(hipMemcpyAsync(words.data(), c->ri_flow, sizeof(uint32_t) * words.size(), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            *pushed = *finished = 0;
+            for (uint32_t o = 0; o < owners; ++o) {
+                *pushed += words[REINIT_FLOW_TAIL(o)];
+                *finished += words[REINIT_FLOW_DONE(o)];
+            }
+            return SPH_OK;
+        };
+        uint64_t done_before = 0;
+        for (uint64_t round = 0;; ++round) {
+            HIPCHK(hipMemsetAsync(c->ri_flow, 0, sizeof(uint32_t), c->stream)); /* the stop flag */
+            uint32_t stop_word = 0;
+            if (c->ri_take_turns) {
+                /* ranks that share a GPU: two walks that each hold part of the chip would wait for
+                 * workgroups the other one keeps out; one rank at a time */
+                for (int turn = 0; turn < c->nranks; ++turn) {
+                    if (turn == c->rank) CHK(reinit_flow_launch(c, r, ids, owners, qseg, gran, 1, &stop_word));
+                    double token[1] = {0.0};
+                    CHK(allreduce_host(c, token, 1, 1));
+                }
+            } else {
+                CHK(reinit_flow_launch(c, r, ids, owners, qseg, gran, 1, &stop_word));
+            }
+            /* a rank whose walk gave up still takes part in the round's exchanges, then all stop */
+            uint64_t pushed = 0, done_now = 0;
+            CHK(read_counts(&pushed, &done_now));
+            uint2* const sb = (uint2*)c->sendbuf;
+            uint2* const rb = (uint2*)c->recvbuf;
+            for (int side = 0; side < 2; ++side)
+                if (c->nsend[side])
+                    hipLaunchKernelGGL(k_reinit_pack_flow, dim3(nblk(c->nsend[side])), dim3(SPH_BLOCK), 0, c->stream, gran, c->ri_gen,
+                                       c->send_idx + side * hc, c->nsend[side], sb + side * hc);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev_packed, c->stream));
+            HIPCHK(hipStreamWaitEvent(c->comm, c->ev_packed, 0));
+            CHK(exchange_bytes(c, sb, (size_t)c->nsend[0] * sizeof(uint2), rb, (size_t)c->nrecv[0] * sizeof(uint2), sb + hc,
+                               (size_t)c->nsend[1] * sizeof(uint2), rb + hc, (size_t)c->nrecv[1] * sizeof(uint2)));
+            HIPCHK(hipEventRecord(c->ev_recvd, c->comm));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_recvd, 0));
+            if (c->nrecv[0])
+                hipLaunchKernelGGL(k_reinit_unpack_flow, dim3(nblk(c->nrecv[0])), dim3(SPH_BLOCK), 0, c->stream, rb, c->halo_pos,
+                                   c->nrecv[0], r, gran, c->ri_gen);
+            if (c->nrecv[1])
+                hipLaunchKernelGGL(k_reinit_unpack_flow, dim3(nblk(c->nrecv[1])), dim3(SPH_BLOCK), 0, c->stream, rb + hc,
+                                   c->halo_pos + c->nrecv[0], c->nrecv[1], r, gran, c->ri_gen);
+            if (c->dim == 3)
+                hipLaunchKernelGGL(k_reinit_rescan_flow<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
+                                   c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, touches, gran, c->ri_gen, owners, qseg);
+            else
+                hipLaunchKernelGGL(k_reinit_rescan_flow<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
+                                   c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, touches, gran, c->ri_gen, owners, qseg);
+            HIPCHK(hipGetLastError());
+            uint64_t pushed_after = 0, done_same = 0;
+            CHK(read_counts(&pushed_after, &done_same));
+            /* all ranks: particles not finished yet, whether this round moved anything, and whether
+             * any rank's walk gave up */
+            double v[3] = {(double)(n - done_now), (double)(done_now - done_before) + (double)(pushed_after - done_now),
+                           stop_word == REINIT_STOP_GAVE_UP ? 1.0 : 0.0};
+            CHK(allreduce_host(c, v, 3, 1));
+            c->reinit_rounds = round + 1;
+            if (v[2] != 0.0) {
+                *stalled = true;
+                return fail(c, SPH_ESTATE, "density re-initialisation: a rank's one-launch walk gave up");
+            }
+            if (v[0] == 0.0) break;
+            if (v[1] == 0.0) return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
+            done_before = done_now;
+        }
+    } else if (c->dist) {
         /* The walk is in global index order, so a particle may wait for one of a neighbouring
          * rank.  Rounds: every rank walks as far as its own particles allow; the ranks then tell
          * their neighbours the new rho of the shared particles that are finished, each recounts
@@ -1956,6 +2097,7 @@ int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
             done_before = done_now;
         }
     } else if (n <= REINIT_SINGLE_MAX) { /* a small case is walked by one workgroup, level after level */
+        ++c->reinit_launches;
         if (c->dim == 3)
             hipLaunchKernelGGL(k_reinit_single<3>, dim3(1), dim3(REINIT_SINGLE_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
                                c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl);
@@ -1968,49 +2110,11 @@ int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
         if (h->done != n || h->cnt[0] != n)
             return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
     } else if (owners) {
-        const uint64_t limit = (uint64_t)(c->ri_limit_s * 1e8); /* ticks of the 100 MHz clock */
         unsigned long long* const gran = (unsigned long long*)(c->ri_queue + (((size_t)owners * qseg + 1) & ~(size_t)1));
-        if (c->dim == 3)
-            hipLaunchKernelGGL(k_reinit_flow<3>, dim3(owners), dim3(REINIT_FLOW_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
-                               c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, qseg, limit, gran, c->ri_gen);
-        else
-            hipLaunchKernelGGL(k_reinit_flow<2>, dim3(owners), dim3(REINIT_FLOW_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
-                               c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, qseg, limit, gran, c->ri_gen);
-        HIPCHK(hipGetLastError());
-        ++c->reinit_launches;
         if (c->trace) fprintf(stderr, "[sph] reinit: one-launch walk, %u workgroups, %u places each, call %u\n", owners, qseg, c->ri_gen);
-        HIPCHK(hipMemcpyAsync(h, c->ri_flow, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        {
-            /* the waves give up by themselves after `limit`; should the launch outlive that by far,
-             * the host raises the stop flag from a second stream */
-            const auto t_start = std::chrono::steady_clock::now();
-            bool raised = false;
-            for (;;) {
-                const hipError_t q = hipStreamQuery(c->stream);
-                if (q == hipSuccess) break;
-                if (q != hipErrorNotReady) HIPCHK(q);
-                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-                if (!raised && waited > 2.0 * c->ri_limit_s + 5.0) {
-                    hipStream_t side;
-                    HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-                    static const uint32_t one = 1;
-                    HIPCHK(hipMemcpyAsync(c->ri_flow, &one, sizeof one, hipMemcpyHostToDevice, side));
-                    HIPCHK(hipStreamSynchronize(side));
-                    HIPCHK(hipStreamDestroy(side));
-                    raised = true;
-                    fprintf(stderr, "[sph] density re-initialisation: stop flag raised by the host after %.1f s\n", waited);
-                }
-                if (waited > 4.0 * c->ri_limit_s + 20.0) {
-                    c->lost = true;
-                    c->ri_owners = 0;
-                    return fail(c, SPH_ESTATE, "density re-initialisation does not come back; the context is lost "
-                                               "(its stream still holds the launch: end the process with a failure code)");
-                }
-                if (waited > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(200));
-            }
-        }
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (*(const uint32_t*)h != 0) {
+        uint32_t stop_word = 0;
+        CHK(reinit_flow_launch(c, r, ids, owners, qseg, gran, 0, &stop_word));
+        if (stop_word != 0) {
             *stalled = true; /* every wave has left: the caller may walk again, by levels */
             return fail(c, SPH_ESTATE, "density re-initialisation stalled before every particle was done");
         }
@@ -2058,8 +2162,35 @@ int sph_density_reinit(sph_ctx* c) {
         if (const char* e = getenv("SPH_REINIT_WALK")) {
             if (!strcmp(e, "levels")) c->ri_owners = 0;
         }
+        /* fewer workgroups (tests: several ranks' walks on one GPU at the same time) */
+        if (const char* e = getenv("SPH_REINIT_OWNERS"))
+            if (c->ri_owners) c->ri_owners = (uint32_t)std::min<long>(c->ri_owners, std::max<long>(1, atol(e)));
         if (const char* e = getenv("SPH_REINIT_LIMIT_S")) c->ri_limit_s = std::max(1e-6, atof(e));
         if (c->ri_owners) CHK(dalloc(c, &c->ri_flow, REINIT_FLOW_WORDS(c->ri_owners)));
+        if (c->dist) {
+            /* Ranks that share a GPU (test set-ups) cannot all have their walk's workgroups on the
+             * chip together: they then walk one after the other.  Every rank tells the others which
+             * GPU of which machine it runs on. */
+            char host[256] = {0};
+            gethostname(host, sizeof host - 1);
+            uint32_t hh = 2166136261u;
+            for (const char* p = host; *p; ++p) hh = (hh ^ (uint8_t)*p) * 16777619u;
+            std::vector<double> where(2 * (size_t)c->nranks, 0.0);
+            where[2 * c->rank] = (double)hh;
+            where[2 * c->rank + 1] = (double)(((uint32_t)prop.pciDomainID << 16) | ((uint32_t)prop.pciBusID << 8) | (uint32_t)prop.pciDeviceID) + 1.0;
+            CHK(allreduce_host(c, where.data(), 2 * c->nranks, 1));
+            for (int k = 0; k < c->nranks; ++k)
+                if (k != c->rank && where[2 * k] == where[2 * c->rank] && where[2 * k + 1] == where[2 * c->rank + 1])
+                    c->ri_take_turns = true;
+            if (const char* e = getenv("SPH_REINIT_TURNS")) c->ri_take_turns = atoi(e) != 0;
+            /* all ranks walk the same way */
+            double agree[2] = {c->ri_owners ? 0.0 : 1.0, c->ri_take_turns ? 1.0 : 0.0};
+            CHK(allreduce_host(c, agree, 2, 0));
+            if (agree[0] != 0.0) c->ri_owners = 0;
+            c->ri_take_turns = agree[1] != 0.0;
+            if (c->trace) fprintf(stderr, "[sph] reinit: rank %d of %d, %s%s\n", c->rank, c->nranks,
+                                  c->ri_owners ? "one-launch walk in rounds" : "walk by levels", c->ri_take_turns ? ", one rank at a time" : "");
+        }
     }
     /* complete lists (wall-wall pairs included) on the positions of state n+1; a slab run
      * fetches its neighbours' particles with them */
@@ -2067,17 +2198,20 @@ int sph_density_reinit(sph_ctx* c) {
     const uint32_t n = c->n;
     Rec* r = c->rec[c->b0];
     bool stalled = false;
-    if (!c->dist && n > REINIT_SINGLE_MAX && c->ri_owners) {
+    c->reinit_launches = c->reinit_rounds = 0;
+    if (c->ri_owners && (c->dist || n > REINIT_SINGLE_MAX)) {
         /* The one-launch walk needs every one of its workgroups on the chip at once.  Should it
          * give up (compute units taken by somebody else's work), rho goes back to what it was
-         * and this context walks by levels from now on. */
+         * and this context walks by levels from now on.  In a slab run every rank hears of one
+         * rank's giving up in the same round, and all of them change over together. */
         float* const keep = (float*)c->tmp;
-        hipLaunchKernelGGL(k_rho_copy, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, r, keep, n, 0);
+        const uint32_t held = n + c->n_halo; /* the neighbours' particles take the ranks' news in place */
+        hipLaunchKernelGGL(k_rho_copy, dim3(nblk(held)), dim3(SPH_BLOCK), 0, c->stream, r, keep, held, 0);
         const int rc = reinit_walk(c, true, &stalled);
         if (rc != SPH_OK && !stalled) return rc;
         if (stalled) {
             fprintf(stderr, "[sph] density re-initialisation: the one-launch walk gave up; walking by levels\n");
-            hipLaunchKernelGGL(k_rho_copy, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, r, keep, n, 1);
+            hipLaunchKernelGGL(k_rho_copy, dim3(nblk(held)), dim3(SPH_BLOCK), 0, c->stream, r, keep, held, 1);
             c->ri_owners = 0;
             CHK(reinit_walk(c, false, &stalled));
         }
@@ -2088,6 +2222,15 @@ int sph_density_reinit(sph_ctx* c) {
     hipLaunchKernelGGL(k_fix_prr, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, r, c->pp, n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_reinit_info(sph_ctx* c, uint64_t* out4) {
+    if (!c || !out4) return SPH_EINVAL;
+    out4[0] = c->reinit_walked;
+    out4[1] = c->reinit_launches;
+    out4[2] = c->reinit_rounds;
+    out4[3] = c->ri_take_turns ? 1u : 0u;
     return SPH_OK;
 }
 

@@ -1885,8 +1885,12 @@ __device__ __forceinline__ bool fullpiv_solve_e0(double (&lu)[N][N], double (&be
 #define REINIT_DONE 0x80000000u
 
 /* The one-launch walk (k_reinit_flow) keeps one queue per workgroup; its control words: word 0 is
- * the stop flag, the tail of queue o sits 64 bytes apart from the others */
+ * the stop flag (1: a wave gave up; 2: a slab's partial walk has run dry), the tail of queue o sits
+ * 64 bytes apart from the others, and beside it the number of queue o's entries that are finished */
 #define REINIT_FLOW_TAIL(o) (16u * (1u + (o)))
+#define REINIT_FLOW_DONE(o) (16u * (1u + (o)) + 1u)
+#define REINIT_STOP_GAVE_UP 1u
+#define REINIT_STOP_DRY 2u
 #define REINIT_FLOW_WORDS(owners) (16u * (1u + (owners)))
 #define REINIT_EMPTY 0xFFFFFFFFu
 
@@ -2342,17 +2346,48 @@ __global__ __launch_bounds__(REINIT_LEVEL_THREADS) void k_reinit_level(DevParams
  * owns), when the stop flag is up, or when it has waited `limit` ticks of the 100 MHz clock
  * for one thing (it raises the flag; the host reports the walk as stalled). */
 #define REINIT_FLOW_THREADS 1024
+/* Slab runs walk in rounds (`partial`): a particle that waits for a neighbouring rank's particle is
+ * not released, so a rank's queues do not fill up and "my places are used up" never comes.  The
+ * round is over when the walk has run dry: every entry ever pushed is finished, in every queue.
+ * Each queue counts its pushes (its tail) and its finished entries; a particle pushes the ones it
+ * sets free BEFORE it is counted as finished itself, so while anything is in work some queue has
+ * fewer finished entries than pushes.  A watcher looks over all the queues
+ * twice: if every queue's two counts are equal both times and the sum of the tails has not moved
+ * in between, there was an instant (the end of the first pass) at which nothing was in work -- and
+ * nothing can start without something in work.  The first wave of workgroup 0 does nothing but
+ * this, and raises the stop flag with REINIT_STOP_DRY. */
+__device__ __forceinline__ bool reinit_flow_dry(const uint32_t* __restrict__ flow, uint32_t owners, uint32_t lane) {
+    unsigned long long tails[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        unsigned long long sum = 0;
+        bool equal = true;
+        for (uint32_t o = lane; o < owners; o += 64u) {
+            const uint32_t t = __hip_atomic_load(flow + REINIT_FLOW_TAIL(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t d = __hip_atomic_load(flow + REINIT_FLOW_DONE(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            equal = equal && t == d;
+            sum += t;
+        }
+        if (__ballot(!equal) != 0ull) return false;
+#pragma unroll
+        for (int w = 32; w > 0; w >>= 1) sum += __shfl_xor(sum, w);
+        tails[pass] = sum;
+    }
+    return tails[0] == tails[1];
+}
+
 template <int DIM>
 __global__ __launch_bounds__(REINIT_FLOW_THREADS) void k_reinit_flow(DevParams P, Rec* __restrict__ rec,
                                                                      const uint32_t* __restrict__ nbr, uint32_t stride,
                                                                      const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
                                                                      uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
                                                                      uint32_t* __restrict__ flow, uint32_t qseg, uint64_t limit,
-                                                                     unsigned long long* __restrict__ gran, uint32_t gen) {
+                                                                     unsigned long long* __restrict__ gran, uint32_t gen, int partial) {
     __shared__ uint32_t s_head;
     const uint32_t o = blockIdx.x, owners = gridDim.x;
     const uint32_t mine = P.n > o ? (P.n - o + owners - 1u) / owners : 0u;
-    if (threadIdx.x == 0) s_head = 0;
+    /* a round of a slab's walk goes on where the last one ended: behind the finished entries */
+    if (threadIdx.x == 0) s_head = partial ? flow[REINIT_FLOW_DONE(o)] : 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t* const myq = queue + (size_t)o * qseg;
@@ -2364,6 +2399,17 @@ __global__ __launch_bounds__(REINIT_FLOW_THREADS) void k_reinit_flow(DevParams P
     /* every branch is on a value made wave-uniform by hand; the loops have one way out */
     auto uniform = [](bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; };
     bool run = true;
+    if (partial && o == 0 && threadIdx.x < 64u) {
+        /* the round's watcher: this wave takes no particles.  It leaves when the stop flag is up:
+         * raised by itself (dry -- which is also how a finished walk looks) or by a wave that gave up */
+        while (run) {
+            __builtin_amdgcn_s_sleep(8);
+            if (uniform(reinit_flow_dry(flow, owners, lane)) && lane == 0)
+                __hip_atomic_store(flow, REINIT_STOP_DRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            run = !uniform(__hip_atomic_load(flow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+        }
+        return;
+    }
     while (run) {
         uint32_t h = 0;
         if (lane == 0) h = atomicAdd(&s_head, 1u);
@@ -2381,7 +2427,7 @@ __global__ __launch_bounds__(REINIT_FLOW_THREADS) void k_reinit_flow(DevParams P
                 if (uniform((++spins & 15u) == 0u)) {
                     const bool stop = uniform(__hip_atomic_load(flow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
                     const bool late = uniform(wall_clock64() - t0 > limit);
-                    if (late && lane == 0) __hip_atomic_store(flow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (late && !stop && lane == 0) __hip_atomic_store(flow, REINIT_STOP_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (stop || late) {
                         run = false;
                         waiting = false;
@@ -2395,6 +2441,58 @@ __global__ __launch_bounds__(REINIT_FLOW_THREADS) void k_reinit_flow(DevParams P
             const uint32_t slot = atomicAdd(flow + REINIT_FLOW_TAIL(own), 1u);
             __hip_atomic_store(queue + (size_t)own * qseg + slot, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }, fl);
+        /* finished (its pushes were made at its start): only now does it stop counting as in work */
+        if (partial && run && lane == 0) atomicAdd(flow + REINIT_FLOW_DONE(o), 1u);
+    }
+}
+
+/* Slab runs, between two rounds of the one-launch walk.  A particle is finished when its published
+ * word carries this call's tag.  The neighbours are told the new rho of the finished particles they
+ * see; what they report is published here under the same tag; and the waiting particles next to a
+ * neighbour's particle are recounted -- the round has run dry, so nothing else touches pend[] now,
+ * and every released particle is finished -- and pushed into their owners' queues when free. */
+__global__ __launch_bounds__(SPH_BLOCK) void k_reinit_pack_flow(const unsigned long long* __restrict__ gran, uint32_t gen,
+                                                                const uint32_t* __restrict__ idx, uint32_t m,
+                                                                uint2* __restrict__ out) {
+    const uint32_t k = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (k >= m) return;
+    const unsigned long long g = gran[idx[k]];
+    out[k] = make_uint2((uint32_t)g, (uint32_t)(g >> 32) == gen ? 1u : 0u);
+}
+__global__ __launch_bounds__(SPH_BLOCK) void k_reinit_unpack_flow(const uint2* __restrict__ in, const uint32_t* __restrict__ pos,
+                                                                  uint32_t m, Rec* __restrict__ rec,
+                                                                  unsigned long long* __restrict__ gran, uint32_t gen) {
+    const uint32_t k = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t slot = pos[k];
+    if (in[k].y && (uint32_t)(gran[slot] >> 32) != gen) {
+        rec[slot].rho = __uint_as_float(in[k].x);
+        gran[slot] = ((unsigned long long)gen << 32) | in[k].x;
+    }
+}
+template <int DIM>
+__global__ __launch_bounds__(SPH_BLOCK) void k_reinit_rescan_flow(DevParams P, const Rec* __restrict__ rec,
+                                                                  const uint32_t* __restrict__ nbr, uint32_t stride,
+                                                                  const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ id,
+                                                                  uint32_t* __restrict__ pend, uint32_t* __restrict__ queue,
+                                                                  uint32_t* __restrict__ flow, const uint32_t* __restrict__ touches,
+                                                                  const unsigned long long* __restrict__ gran, uint32_t gen,
+                                                                  uint32_t owners, uint32_t qseg) {
+    const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
+    if (i >= P.n || !touches[i] || (uint32_t)(gran[i] >> 32) == gen) return;
+    const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi = DIM == 3 ? rec[i].xv[2][0] : 0.0;
+    const uint32_t me = id[i], c = cnt[i];
+    uint32_t lower = 0;
+    for (uint32_t k = 0; k < c; ++k) {
+        const uint32_t j = nbr[(size_t)i * stride + k];
+        const double d2 = dist2_exact(rec[j].xv[0][0] - xi, rec[j].xv[1][0] - yi, DIM == 3 ? rec[j].xv[2][0] - zi : 0.0);
+        if (d2 < P.R2 && id[j] < me && (uint32_t)(gran[j] >> 32) != gen) ++lower;
+    }
+    if (lower == pend[i]) return; /* nothing new next to this one (it is still waiting) */
+    pend[i] = lower;
+    if (lower == 0) {
+        const uint32_t o = i % owners;
+        queue[(size_t)o * qseg + atomicAdd(flow + REINIT_FLOW_TAIL(o), 1u)] = i;
     }
 }
 

@@ -92,6 +92,8 @@ def main():
             sc = sim.step(k)
             done += k
             sim.density_reinit()
+        info = sim.reinit_info()
+        res["reinit_info"] = np.array([info["walk"], info["launches"], info["rounds"], int(info["took_turns"])])
     else:
         syncs0 = sim.scalars()["host_syncs"]
         sc = sim.step(args.steps)

@@ -297,10 +297,38 @@ def test_device_buffer_transport(name, nranks, vx, tmp_path):
 # after the call (the two sum a particle's neighbours in different orders), and the usual bars
 # after the main loop has gone on from there.
 
+# Two ways through it: a rank's walk as one launch per round of exchanges (queues per workgroup; the
+# ranks of these tests share the GPU and so take turns), or one launch per dependency level.
+
+def reinit_walk_ran(res, walk, monkeypatch=None):
+    from sph_amd import capi
+    kind, launches, rounds, turns = (int(v) for v in res["reinit_info"])
+    print("DensityReinit: walk %d, %d launches, %d rounds%s" % (kind, launches, rounds, ", ranks in turn" if turns else ""))
+    if walk == "levels":
+        assert kind == capi.REINIT_LEVELS and launches >= 16 * rounds
+    else:
+        # one launch a round (rank 0 is what the file holds); left alone, the ranks find out that
+        # they share the GPU
+        assert kind == capi.REINIT_ONE_LAUNCH_ROUNDS and launches == rounds >= 1
+        assert turns == (0 if walk == "flow_together" else 1)
+
+
+def choose_walk(monkeypatch, walk):
+    monkeypatch.setenv("SPH_REINIT_WALK", "levels" if walk == "levels" else "flow")
+    if walk == "flow_together":
+        # what ranks with a GPU each do -- all walks at the same time -- with few enough
+        # workgroups each for the walks of three ranks to be on this one GPU together
+        monkeypatch.setenv("SPH_REINIT_TURNS", "0")
+        monkeypatch.setenv("SPH_REINIT_OWNERS", "64")
+
+
+@pytest.mark.parametrize("walk", ["flow", "flow_together", "levels"])
 @pytest.mark.parametrize("name,nranks", [("wcxsph3d_block", 2), ("wcxsph_fine", 3), ("wcsph_fine", 2)])
-def test_density_reinit_across_slabs(name, nranks, tmp_path):
+def test_density_reinit_across_slabs(name, nranks, walk, tmp_path, monkeypatch):
+    choose_walk(monkeypatch, walk)
     spec = util.small_cases()[name]
     res = run_slabs(spec, nranks, tmp_path, steps=6, reinit=3)
+    reinit_walk_ran(res, walk)
     oc, _ = util.both_cases(spec)
     orc = O.Oracle(oc)
     orc.forces(O.STATE_N)
@@ -318,10 +346,13 @@ def test_density_reinit_across_slabs(name, nranks, tmp_path):
     assert util.float_ulp_diff(res["step_rho"], o["rho"]).max() <= 1
 
 
-def test_density_reinit_across_slabs_with_particles_changing_owner(tmp_path):
+@pytest.mark.parametrize("walk", ["flow", "flow_together"])
+def test_density_reinit_across_slabs_with_particles_changing_owner(walk, tmp_path, monkeypatch):
     # a droplet moving in x: particles cross the plane between the frames' re-initialisations
+    choose_walk(monkeypatch, walk)
     spec = util.drop_cases()["droplet3d"]
     res = run_slabs(spec, 2, tmp_path, steps=6, reinit=2, skin=0.05)
+    reinit_walk_ran(res, walk)
     oc, _ = util.both_cases(spec)
     orc = O.Oracle(oc)
     orc.forces(O.STATE_N)
@@ -333,6 +364,30 @@ def test_density_reinit_across_slabs_with_particles_changing_owner(tmp_path):
     o = orc.get_state(O.STATE_N)
     for k in ("x", "v", "f"):
         assert util.rel_err(res["step_" + k].T, o[k]) <= TOL, k
+
+
+@pytest.mark.parametrize("walk", ["flow", "flow_together"])
+def test_density_reinit_of_a_medium_size_case_on_two_slabs(walk, tmp_path, monkeypatch):
+    # ~0.57 M particles, dependency chains of thousands of particles crossing the plane several
+    # times: against the single-domain HIP walk (itself checked against the oracle at small sizes)
+    from sph_amd import capi
+    choose_walk(monkeypatch, walk)
+    spec = dict(program=2, npart=(160, 80, 24), pstep=0.1, box=(32.3, 8.3, 4.8), start=(0.15, 0.15, 0.15))
+    res = run_slabs(spec, 2, tmp_path, steps=2, reinit=2)
+    reinit_walk_ran(res, walk)
+    assert int(res["reinit_info"][2]) >= 2  # the walk did wait for the neighbour
+    _, pc = util.both_cases(spec)
+    sim = capi.Sim.from_case(pc)
+    sim.forces(capi.STATE_N)
+    sim.zero_boundary_forces(capi.STATE_N)
+    sim.step(2)
+    sim.density_reinit()
+    assert sim.reinit_info()["walk"] == capi.REINIT_ONE_LAUNCH
+    rho = sim.download(capi.STATE_NP1, names=("rho",))["rho"]
+    sim.close()
+    u = util.float_ulp_diff(res["step_np1_rho"], rho)
+    print("0.57 M particles on 2 slabs: DensityReinit rho max ulp %d, differing %d of %d" % (u.max(), int((u > 0).sum()), len(u)))
+    assert u.max() <= 1
 
 
 def test_rccl_calls_on_a_one_rank_communicator():

@@ -23,7 +23,10 @@ for k in range(2):
     sim.density_reinit()
     dt = time.perf_counter() - t0
     if rank == 0:
-        print("%d ranks, %d particles (%d on rank 0): DensityReinit %.1f ms, %d exchanges" % (world, sim.npts_global, sim.npts, dt * 1e3, tr.exchanges - e0), flush=True)
+        info = sim.reinit_info()
+        print("%d ranks, %d particles (%d on rank 0): DensityReinit %.1f ms, %d exchanges; walk %d, %d launches, %d rounds%s"
+              % (world, sim.npts_global, sim.npts, dt * 1e3, tr.exchanges - e0, info["walk"], info["launches"], info["rounds"],
+                 ", ranks in turn" if info["took_turns"] else ""), flush=True)
     sim.step(1)
 sim.close()
 dist.barrier()
