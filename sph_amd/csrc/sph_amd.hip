@@ -1002,6 +1002,7 @@ NState n_state(sph_ctx* c) {
     }
     s.rho = c->nfl[F_RHO];
     s.Rrho = c->nfl[F_RRHO];
+    s.p = c->nfl[F_P];
     return s;
 }
 
@@ -1135,12 +1136,13 @@ void fill_scalars(sph_ctx* c, sph_scalars* out) {
 /* One sweep's pair/update launches.  A single domain is one launch.  A slab first does the
  * layers next to its neighbours, hands their new records to the transport on the
  * communication stream, and computes its interior while they travel. */
-int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, uint32_t* part_n_out) {
+int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, bool commit, uint32_t* part_n_out) {
     const uint32_t n = c->n;
     OutState o = out_state(c, SPH_STATE_NP1);
     if (!c->dist) {
+        /* commit: the launch also writes state n (see k_pair, store_out == 2) */
         *part_n_out = pairgrid(n);
-        return launch_sweep(c, c->rec[cur], c->rec[nxt], o, last ? 1 : 0, 0, n, 0, *part_n_out);
+        return launch_sweep(c, c->rec[cur], c->rec[nxt], o, last ? (commit ? 2 : 1) : 0, 0, n, 0, *part_n_out);
     }
     const uint32_t nL = c->iL_end, nR = n - c->iR_begin, nI = c->iR_begin - c->iL_end;
     const uint32_t bL = pairgrid(nL), bR = pairgrid(nR), bI = pairgrid(nI);
@@ -1251,7 +1253,9 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
                 HIPCHK(hipEventRecord(ev->a, c->stream));
             }
             uint32_t part_n = 0;
-            CHK(sweep_launches(c, cur, nxt, last, &part_n));
+            /* a single domain's last sweep commits the step itself; ranks first agree on whether
+             * the step stands (below), and k_commit follows */
+            CHK(sweep_launches(c, cur, nxt, last, last && !partial && !c->dist, &part_n));
             if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
             hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS, PART_FIELDS), dim3(SPH_BLOCK), 0, c->stream, c->part_use, part_n, PART_FIELDS,
                                c->part2_use);
@@ -1299,7 +1303,7 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             hipLaunchKernelGGL(k_apply_global, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->red_dev, partial ? 0 : 1);
         }
         if (!partial) {
-            hipLaunchKernelGGL(k_commit, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, a, c->S);
+            if (c->dist) hipLaunchKernelGGL(k_commit, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, a, c->S);
             hipLaunchKernelGGL(k_commit_scalars, dim3(1), dim3(1), 0, c->stream, c->S);
         }
         HIPCHK(hipGetLastError());

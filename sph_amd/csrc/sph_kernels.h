@@ -879,6 +879,7 @@ struct NState { /* state n, structure of arrays, cell order */
     const double* f[3];
     const float* rho;
     const float* Rrho;
+    const float* p; /* only written: by the sweep that also commits the step */
 };
 
 struct OutState { /* f, V, Rrho produced by Forces */
@@ -1040,9 +1041,15 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
     uint32_t hits = 0; /* wave total, kept on the scalar side */
     /* the time step of this sweep: read once, ahead of everything, and kept on the scalar side */
     double dt = 0.0;
+    /* store_out == 2: the step's last sweep in a single domain also makes state n+1 the new state n
+     * (pn = pnp1, WCXSPH3D.cpp:301) unless the step has to be made again.  No earlier sweep of a step
+     * is left unchecked and the last one is not checked at all, so the flag is final when this
+     * launch starts.  A particle's state n is read by its own lane only, before that lane writes it. */
+    bool commit = false;
     if (FUSED) {
         const double v = S->dt;
         dt = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+        commit = store_out == 2 && __builtin_amdgcn_readfirstlane(S->violation) == 0;
     }
 
     for (uint32_t g = 0; g < PAIR_GROUPS; ++g) {
@@ -1295,6 +1302,12 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
                 const double ex = xnew - xo[d];
                 f2 += fd[d] * fd[d];
                 move2 += ex * ex;
+                if (commit && mine) {
+                    stream_store(const_cast<double*>(ns.x[d]) + e, xnew);
+                    stream_store(const_cast<double*>(ns.v[d]) + e, w[d].y);
+                    stream_store(const_cast<double*>(ns.f[d]) + e, fd[d]);
+                    if (XSPH) stream_store(const_cast<double*>(ns.V[d]) + e, Vd[d]);
+                }
             }
         }
         const float Rrho_n = stream_load(ns.Rrho + e), rho_n = stream_load(ns.rho + e);
@@ -1305,6 +1318,11 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
             (long long)(((unsigned long long)__float_as_uint(m_f) << 32) | (unsigned long long)__float_as_uint(rho_new)));
         w[3].y = (double)p_new / ((double)rho_new * (double)rho_new);
         if (mine) stream_store(pout + e, p_new);
+        if (commit && mine) {
+            stream_store(const_cast<float*>(ns.rho) + e, rho_new);
+            stream_store(const_cast<float*>(ns.p) + e, p_new);
+            stream_store(const_cast<float*>(ns.Rrho) + e, Rrho_f);
+        }
         /* The new records leave as whole kilobytes: particle s lays its four chunks into the
          * transpose area (block s/16, record s%16), and the wave stores each block lane-linear --
          * 16 whole records per instruction. */

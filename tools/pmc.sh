@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counter passes over a short bench run (one rocprofv3 run per pass; counters only).
-# usage: tools/pmc.sh <outdir> [bench args...]
+# usage: [KERNEL=regex] [PASSES="sq1 ta"] tools/pmc.sh <outdir> [bench args...]     (KERNEL defaults to k_pair)
 set -u
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -9,7 +9,7 @@ mkdir -p "$out"
 run() {
   name=$1; ctrs=$2; shift 2
   if [ -n "${PASSES:-}" ] && ! [[ " $PASSES " == *" $name "* ]]; then return 0; fi
-  timeout -s KILL 180 rocprofv3 --pmc $ctrs --kernel-include-regex "k_pair" --output-format csv -d "$out/$name" -- python bench.py --steps 2 --warmup 1 --no-cpu "$@" > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$out/$name.log"; return 1; }
+  timeout -s KILL 180 rocprofv3 --pmc $ctrs --kernel-include-regex "${KERNEL:-k_pair}" --output-format csv -d "$out/$name" -- python bench.py --steps 2 --warmup 1 --no-cpu "$@" > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$out/$name.log"; return 1; }
   echo "pass $name ok"
 }
 run sq1 "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "$@" &&

@@ -1,17 +1,15 @@
-"""Summarise rocprofv3 --pmc CSVs: mean counter value per dispatch of each kernel."""
-import csv
-import glob
-import sys
-from collections import defaultdict
+"""Per-kernel means of the counters that tools/pmc.sh collected: python tools/pmc_summary.py <outdir> [name-regex]"""
+import csv, glob, re, sys, collections
 
-root = sys.argv[1]
-acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(root + "/*/*/*_counter_collection.csv"):
-    with open(f) as fh:
-        for r in csv.DictReader(fh):
-            k = r["Kernel_Name"].split("(")[0]
-            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, cs in acc.items():
-    print(k)
-    for c, v in sorted(cs.items()):
-        print("   %-34s mean %.6g  (n=%d)" % (c, sum(v) / len(v), len(v)))
+out = sys.argv[1]
+pat = re.compile(sys.argv[2] if len(sys.argv) > 2 else ".")
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0]
+        if pat.search(name):
+            acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for name, ctrs in sorted(acc.items()):
+    print(name)
+    for c, v in sorted(ctrs.items()):
+        print("  %-32s n=%-5d mean %.6g  min %.6g  max %.6g" % (c, len(v), sum(v) / len(v), min(v), max(v)))
