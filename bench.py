@@ -33,6 +33,10 @@ FP64_PEAK_TFLOPS = 78.6    # FP64 vector spec
 # cell table 8 B = 104 B.  Algorithmic flops: 80 per pair inside the radius (self included).
 B_ALG_PAIR = 112.0
 B_ALG_UPDATE = 212.0
+# In a single domain the last of a step's eight sweeps also writes state n (pn = pnp1): x, v, f, V
+# 96 B and rho, p, Rrho 12 B per particle, which a slab run's separate commit kernel writes instead.
+B_ALG_COMMIT = 108.0
+SWEEPS_PER_STEP = 8
 B_ALG_REBUILD = 104.0
 FLOP_PER_PAIR = 80.0
 
@@ -194,11 +198,17 @@ class Legs:
         return rest, dev, reinit_ms
 
 
+def pair_bytes_per_particle(single_domain):
+    """Algorithmic bytes per particle of the pair launch, averaged over a step's sweeps."""
+    return B_ALG_PAIR + B_ALG_UPDATE + (B_ALG_COMMIT / SWEEPS_PER_STEP if single_domain else 0.0)
+
+
 def rooflines(n_launch, n_total, dev, pairs_per_particle):
     """`roofline` of the dominant kernel (the fused pair/update launch of a sweep) and of the
     list rebuild, from the launch durations measured with HIP events in the timed region.
     n_launch: particles one launch covers (the slowest rank's in a slab run)."""
-    b_alg = (B_ALG_PAIR + B_ALG_UPDATE) * n_launch
+    per_particle = pair_bytes_per_particle(n_launch == n_total)
+    b_alg = per_particle * n_launch
     ach = b_alg / (dev["pair_ms"] * 1e-3) / 1e9
     f_alg = FLOP_PER_PAIR * pairs_per_particle * n_launch
     ach_tf = f_alg / (dev["pair_ms"] * 1e-3) / 1e12
@@ -208,7 +218,7 @@ def rooflines(n_launch, n_total, dev, pairs_per_particle):
         # what the launch is held by, which is neither of the two roofs
         "bound": "latency", "roof": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
         "traffic": None, "issue": None, "algorithmic_bytes_per_launch": b_alg, "kernel_ms": dev["pair_ms"],
-        "launches": dev["pair_launches"], "algorithmic_bytes_per_particle_sweep": B_ALG_PAIR + B_ALG_UPDATE,
+        "launches": dev["pair_launches"], "algorithmic_bytes_per_particle_sweep": per_particle,
         "limiter": "neither roof binds: a round of the pair loop is a chain -- the quads' gathers land in LDS, are read back transposed, then ~100 "
                    "FP64 instructions -- and a wave has six of them per 16 particles with one round of look-ahead: the waves "
                    "spend over half their life at a wait instruction while the vector ALU is ~2/3 busy and the address units "
@@ -237,7 +247,7 @@ def result_line(args, n_gpus, n, n_launch, workload, rest, dev, reinit_ms, scali
     frame_ms = 10 * dev["ms_per_step"] + reinit_ms
     cfg = {
         "workload": workload,
-        "particles": n, "sweeps_per_step": 8, "force_evals_per_s": value * 8,
+        "particles": n, "sweeps_per_step": SWEEPS_PER_STEP, "force_evals_per_s": value * SWEEPS_PER_STEP,
         "flow": "developed: %d steps advanced untimed before the warm-up (t = %.3f s at the end of the timed region)"
                 % (args.preroll, dev["t"]),
         "pairs_in_radius_per_particle": pairs,
@@ -248,7 +258,7 @@ def result_line(args, n_gpus, n, n_launch, workload, rest, dev, reinit_ms, scali
         "at_rest": {
             "value": n * rest["steps"] / rest["elapsed"], "steps": rest["steps"], "ms_per_step": rest["ms_per_step"],
             "pair_kernel_ms": rest["pair_ms"], "list_rebuilds": rest["rebuilds"],
-            "roofline_frac": (B_ALG_PAIR + B_ALG_UPDATE) * n_launch / (rest["pair_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline_frac": pair_bytes_per_particle(n_launch == n) * n_launch / (rest["pair_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "the lattice at rest from t = 0: no list rebuild falls into the region (best case)",
         },
         "reinit_ms": reinit_ms,

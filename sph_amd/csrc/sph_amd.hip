@@ -90,6 +90,7 @@ struct sph_ctx {
     double inner_frac = 0.02, r_in2 = 0, limit_in = 0, outer_budget = 0;
     bool two_level = false;        /* decided at each rebuild */
     bool step_lists_valid = false; /* nbr_in serves the positions state n+1 holds now */
+    bool np1_out_in_n = false;     /* f, V, Rrho of state n+1 exist only as state n's (see settle_np1_outputs) */
     double in_travel = 0;          /* running estimate of the travel between a step's second and last sweep */
     double two_level_min_skin = 0.08, skin_k1 = 2.2, skin_k2 = 12.0, skin_max = 0.5;
     bool skin_k2_auto = true; /* skin_k2 follows the memory left for the list rows (end of sph_create) */
@@ -1006,6 +1007,22 @@ NState n_state(sph_ctx* c) {
     return s;
 }
 
+/* A step that a single domain's last sweep committed leaves f, V and Rrho of state n+1 only in
+ * state n's arrays (pn = pnp1: the same values, written once).  Whoever is about to read state
+ * n+1's arrays, or to change state n's, has them copied first.  The stepping path itself never
+ * reads them. */
+int settle_np1_outputs(sph_ctx* c) {
+    if (!c->np1_out_in_n) return SPH_OK;
+    const size_t n = c->n;
+    for (int d = 0; d < c->dim; ++d) {
+        HIPCHK(hipMemcpyAsync(c->pd[d], c->nd[NF(d)], n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        if (c->xsph) HIPCHK(hipMemcpyAsync(c->pd[3 + d], c->nd[NVV(d)], n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(c->pRrho, c->nfl[F_RRHO], n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    c->np1_out_in_n = false;
+    return SPH_OK;
+}
+
 /* An event pair from a pool that grows on demand (nullptr when not profiling, or when the pool is
  * used up in a call that may not allocate). */
 EventPair* take_events(sph_ctx* c, std::vector<EventPair>& pool, size_t& used) {
@@ -1050,7 +1067,7 @@ int launch_sweep(sph_ctx* c, const Rec* rin, Rec* rout, OutState o, int store_ou
 
 /* Draws the step lists from the candidate lists on the positions held in `r` (owned and halo
  * particles), and starts their travel bound. */
-int draw_step_lists(sph_ctx* c, const Rec* r) {
+int draw_step_lists(sph_ctx* c, const Rec* r, bool entries_ready = false) {
     const uint32_t m = c->n + c->n_halo;
     EventPair* ev = nullptr;
     if (c->profile && !(c->no_alloc && c->dr_used == c->dr_pool.size())) {
@@ -1064,7 +1081,9 @@ int draw_step_lists(sph_ctx* c, const Rec* r) {
         HIPCHK(hipEventRecord(ev->a, c->stream));
     }
     const QLattice& L = c->lattice;
-    hipLaunchKernelGGL(k_fill_qpos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, L, c->dim, nullptr, 0u, qpos_of(c));
+    /* entries_ready: the sweep that wrote these records left their lattice entries as well */
+    if (!entries_ready)
+        hipLaunchKernelGGL(k_fill_qpos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, L, c->dim, nullptr, 0u, qpos_of(c));
     /* radius in lattice spacings, widened by the two spacings the rounding can cost */
     const double rq = std::sqrt(c->r_in2) * L.invq + 2.0;
     const uint32_t r2q = (uint32_t)std::ceil(rq * rq);
@@ -1136,10 +1155,14 @@ void fill_scalars(sph_ctx* c, sph_scalars* out) {
 /* One sweep's pair/update launches.  A single domain is one launch.  A slab first does the
  * layers next to its neighbours, hands their new records to the transport on the
  * communication stream, and computes its interior while they travel. */
-int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, bool commit, uint32_t* part_n_out) {
+int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, bool commit, bool entries, uint32_t* part_n_out) {
     const uint32_t n = c->n;
     OutState o = out_state(c, SPH_STATE_NP1);
     if (!c->dist) {
+        if (entries) { /* the draw that follows reads the new positions' lattice entries */
+            o.qpos = qpos_of(c);
+            o.lat = c->lattice;
+        }
         /* commit: the launch also writes state n (see k_pair, store_out == 2) */
         *part_n_out = pairgrid(n);
         return launch_sweep(c, c->rec[cur], c->rec[nxt], o, last ? (commit ? 2 : 1) : 0, 0, n, 0, *part_n_out);
@@ -1255,7 +1278,8 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             uint32_t part_n = 0;
             /* a single domain's last sweep commits the step itself; ranks first agree on whether
              * the step stands (below), and k_commit follows */
-            CHK(sweep_launches(c, cur, nxt, last, last && !partial && !c->dist, &part_n));
+            const bool draw_next = two && k == 0 && !last;
+            CHK(sweep_launches(c, cur, nxt, last, last && !partial && !c->dist, draw_next && !c->dist, &part_n));
             if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
             hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS, PART_FIELDS), dim3(SPH_BLOCK), 0, c->stream, c->part_use, part_n, PART_FIELDS,
                                c->part2_use);
@@ -1269,7 +1293,7 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             }
             hipLaunchKernelGGL(k_sweep_finalize, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->part2_use, k,
                                (last && !partial) ? 1 : (last ? 2 : 0), cand_limit, (two && k >= 1) ? 1 : 0, 0);
-            if (two && k == 0 && !last) CHK(draw_step_lists(c, c->rec[nxt]));
+            if (draw_next) CHK(draw_step_lists(c, c->rec[nxt], !c->dist));
             cur = nxt;
         }
         CommitArgs a;
@@ -1323,6 +1347,8 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             ++c->redos;
             continue;
         }
+        /* the last sweep wrote f, V, Rrho: as state n's when it committed the step, else as state n+1's */
+        c->np1_out_in_n = !partial && !c->dist;
         if (!partial) {
             /* mode 2 restarts the bound at every sweep; what it saw is a lower bound then */
             const double seen = c->disp_host - disp_at_start;
@@ -1688,6 +1714,7 @@ int sph_upload(sph_ctx* c, int32_t which, const sph_fields* s) {
     if (!c || !s) return SPH_EINVAL;
     if (which != SPH_STATE_N && which != SPH_STATE_NP1) return fail(c, SPH_EINVAL, "bad state selector");
     HIPCHK(hipSetDevice(c->device));
+    CHK(settle_np1_outputs(c));
     const int dim = c->dim;
     c->list_valid = false; /* positions or the walls' state may change */
     if (which == SPH_STATE_N) {
@@ -1729,6 +1756,7 @@ int sph_download(sph_ctx* c, int32_t which, const sph_fields* s) {
     if (!c || !s) return SPH_EINVAL;
     if (which != SPH_STATE_N && which != SPH_STATE_NP1) return fail(c, SPH_EINVAL, "bad state selector");
     HIPCHK(hipSetDevice(c->device));
+    CHK(settle_np1_outputs(c));
     const int dim = c->dim;
     if (which == SPH_STATE_N) {
         for (int d = 0; d < dim; ++d) {
@@ -1763,6 +1791,7 @@ int sph_forces(sph_ctx* c, int32_t which) {
     if (which != SPH_STATE_N && which != SPH_STATE_NP1) return fail(c, SPH_EINVAL, "bad state selector");
     if (which == SPH_STATE_N ? !c->uploaded_n : !c->uploaded_np1) return fail(c, SPH_ESTATE, "state was never uploaded");
     HIPCHK(hipSetDevice(c->device));
+    CHK(settle_np1_outputs(c));
     int src = c->b0;
     if (which == SPH_STATE_N) {
         src = (c->b0 + 1) % NREC;
@@ -1793,6 +1822,7 @@ int sph_zero_boundary_forces(sph_ctx* c, int32_t which) {
     if (!c) return SPH_EINVAL;
     if (which != SPH_STATE_N && which != SPH_STATE_NP1) return fail(c, SPH_EINVAL, "bad state selector");
     HIPCHK(hipSetDevice(c->device));
+    CHK(settle_np1_outputs(c));
     OutState o = out_state(c, which);
     hipLaunchKernelGGL(k_zero_wall_f, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, o.f[0], o.f[1], o.f[2], c->dim,
                        wall_ids(c), c->n, c->dp.bound_parts);

@@ -526,19 +526,24 @@ struct QLattice {
     double invq;   /* 1 / spacing */
 };
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
+/* the 8-byte lattice entry of a position (no wall mark) */
+__device__ __forceinline__ uint2 lattice_entry(const QLattice& L, int dim, double x, double y, double z) {
+    auto low16 = [&](double v, double org) -> uint32_t {
+        const double r = rint((v - org) * L.invq);
+        return (uint32_t)(r - 65536.0 * floor(r * (1.0 / 65536.0))) & 0xFFFFu; /* exact: r is an integer */
+    };
+    uint2 p;
+    p.x = low16(x, L.org[0]) | (low16(y, L.org[1]) << 16);
+    p.y = dim == 3 ? low16(z, L.org[2]) : 0u;
+    return p;
+}
 /* id != nullptr: particles whose id is below bound_parts are marked as wall particles */
 __global__ __launch_bounds__(SPH_BLOCK) void k_fill_qpos(const Rec* __restrict__ rec, uint32_t m, QLattice L, int dim,
                                                          const uint32_t* __restrict__ id, uint32_t bound_parts,
                                                          uint2* __restrict__ qpos) {
     const uint32_t i = blockIdx.x * SPH_BLOCK + threadIdx.x;
     if (i >= m) return;
-    auto low16 = [&](double x, double org) -> uint32_t {
-        const double r = rint((x - org) * L.invq);
-        return (uint32_t)(r - 65536.0 * floor(r * (1.0 / 65536.0))) & 0xFFFFu; /* exact: r is an integer */
-    };
-    uint2 p;
-    p.x = low16(rec[i].xv[0][0], L.org[0]) | (low16(rec[i].xv[1][0], L.org[1]) << 16);
-    p.y = dim == 3 ? low16(rec[i].xv[2][0], L.org[2]) : 0u;
+    uint2 p = lattice_entry(L, dim, rec[i].xv[0][0], rec[i].xv[1][0], rec[i].xv[2][0]);
     if (id && id[i] < bound_parts) p.y |= QPOS_WALL;
     qpos[i] = p;
 }
@@ -886,6 +891,10 @@ struct OutState { /* f, V, Rrho produced by Forces */
     double* f[3];
     double* V[3];
     float* Rrho;
+    /* a fused sweep whose new positions the step lists are drawn on next also leaves their lattice
+     * entries (what k_fill_qpos would make of its records); nullptr otherwise */
+    uint2* qpos;
+    QLattice lat;
 };
 
 /* (rho/rho0)^gam - 1 as the reference's pow(rho/rho0, 7.0) - 1 evaluates it: the power is
@@ -1044,7 +1053,9 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
     /* store_out == 2: the step's last sweep in a single domain also makes state n+1 the new state n
      * (pn = pnp1, WCXSPH3D.cpp:301) unless the step has to be made again.  No earlier sweep of a step
      * is left unchecked and the last one is not checked at all, so the flag is final when this
-     * launch starts.  A particle's state n is read by its own lane only, before that lane writes it. */
+     * launch starts.  A particle's state n is read by its own lane only, before that lane writes it.
+     * f, V and Rrho are then written once, as state n's; the host copies them into state n+1's
+     * arrays when somebody asks for those. */
     bool commit = false;
     if (FUSED) {
         const double v = S->dt;
@@ -1274,12 +1285,12 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
             fd[d] = 0.0;
             Vd[d] = 0.0;
         }
-        if (mine && store_out) {
+        if (mine && store_out == 1) {
             stream_store(out.f[d] + e, fd[d]);
             if (XSPH) stream_store(out.V[d] + e, Vd[d]);
         }
     }
-    if (mine && store_out) stream_store(out.Rrho + e, Rrho_f);
+    if (mine && store_out == 1) stream_store(out.Rrho + e, Rrho_f);
     if (FUSED) {
         /* WCXSPH3D.cpp:271-277 */
         const double hdt = 0.5 * dt;
@@ -1318,6 +1329,7 @@ __global__ __launch_bounds__(PAIR_BLOCK, PAIR_WAVES) void k_pair(DevParams P, co
             (long long)(((unsigned long long)__float_as_uint(m_f) << 32) | (unsigned long long)__float_as_uint(rho_new)));
         w[3].y = (double)p_new / ((double)rho_new * (double)rho_new);
         if (mine) stream_store(pout + e, p_new);
+        if (out.qpos != nullptr && mine) out.qpos[e] = lattice_entry(out.lat, DIM, w[0].x, w[1].x, w[2].x);
         if (commit && mine) {
             stream_store(const_cast<float*>(ns.rho) + e, rho_new);
             stream_store(const_cast<float*>(ns.p) + e, p_new);
