@@ -90,6 +90,8 @@ struct sph_ctx {
     double inner_frac = 0.02, r_in2 = 0, limit_in = 0, outer_budget = 0;
     bool two_level = false;        /* decided at each rebuild */
     bool step_lists_valid = false; /* nbr_in serves the positions state n+1 holds now */
+    uint32_t build_trips = BUILD_TRIPS; /* records per particle in the list build (SPH_BUILD_TRIPS; 0: the ring kernel alone) */
+    uint64_t build_handed_on = 0;       /* particles whose rows the ring kernel wrote because their records did not fit */
     bool np1_out_in_n = false;     /* f, V, Rrho of state n+1 exist only as state n's (see settle_np1_outputs) */
     double in_travel = 0;          /* running estimate of the travel between a step's second and last sweep */
     double two_level_min_skin = 0.08, skin_k1 = 2.2, skin_k2 = 12.0, skin_max = 0.5;
@@ -347,24 +349,50 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below, bool with_step_li
     const uint32_t rl2q = (uint32_t)std::ceil(rlq * rlq), rin2q = (uint32_t)std::ceil(rinq * rinq);
     if (c->cap_k & 3u) return fail(c, SPH_ESTATE, "list rows must hold a multiple of four entries");
     for (int attempt = 0; attempt < 4; ++attempt) {
-        HIPCHK(hipMemsetAsync(c->need, 0, sizeof(uint32_t), c->stream));
+        HIPCHK(hipMemsetAsync(c->need, 0, 2 * sizeof(uint32_t), c->stream));
         if (with_step_lists) { /* as many rows again, of the same length */
             bool ok = true;
             CHK(ensure_step_lists(c, &ok));
         }
         uint32_t* const tin = with_step_lists ? c->nbr_in : nullptr;
         uint32_t* const tcnt = with_step_lists ? c->cnt_in : nullptr;
-        if (c->dim == 3)
+        /* the particles whose records do not fit the build's LDS are named here for the ring kernel */
+        uint32_t* const todo = (uint32_t*)c->tmp;
+        /* the ring kernel over the `count` particles of `list` (nullptr: all of them) */
+        auto ring = [&](const uint32_t* list, uint32_t count) {
+            const dim3 grid(list ? (count + PAIR_PARTICLES - 1) / PAIR_PARTICLES : pairblocks(c->n));
+            if (c->dim == 3)
+                hipLaunchKernelGGL(k_build_list_ring<3>, grid, dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid, c->cbeg,
+                                   c->r_list2, rl2q, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, rin2q, tin,
+                                   tcnt, list, count);
+            else
+                hipLaunchKernelGGL(k_build_list_ring<2>, grid, dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid, c->cbeg,
+                                   c->r_list2, rl2q, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, rin2q, tin,
+                                   tcnt, list, count);
+        };
+        if (c->build_trips == 0) {
+            ring(nullptr, 0u);
+        } else if (c->dim == 3) {
             hipLaunchKernelGGL(k_build_list<3>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid,
                                c->cbeg, c->r_list2, rl2q, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, rin2q,
-                               tin, tcnt);
-        else
+                               tin, tcnt, c->build_trips, todo);
+        } else {
             hipLaunchKernelGGL(k_build_list<2>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid,
                                c->cbeg, c->r_list2, rl2q, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, rin2q,
-                               tin, tcnt);
+                               tin, tcnt, c->build_trips, todo);
+        }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->need_host, c->need, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->need_host[1] > 0) {
+            const uint32_t handed_on = c->need_host[1];
+            if (handed_on > c->n) return fail(c, SPH_ESTATE, "list build: more particles handed on than there are");
+            c->build_handed_on += handed_on;
+            ring(todo, handed_on);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
         const uint32_t need = *c->need_host;
         if (need <= c->cap_k) {
             if (c->check_lists) { /* development check: every word of every row names a particle slot */
@@ -975,9 +1003,11 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     c->list_valid = true;
     ++c->rebuilds;
     if (c->trace)
-        fprintf(stderr, "[sph] rebuild %llu: n %u skin %.4f two_level %d inner %.5f step_travel/R %.5f in_travel/R %.3e rows %u\n",
+        fprintf(stderr, "[sph] rebuild %llu: n %u skin %.4f two_level %d inner %.5f step_travel/R %.5f in_travel/R %.3e rows %u "
+                        "handed on %llu\n",
                 (unsigned long long)c->rebuilds, c->n, skin_here, (int)c->two_level, c->inner_frac,
-                c->step_travel / std::sqrt(c->prm.search_radius_sq), c->in_travel / std::sqrt(c->prm.search_radius_sq), c->cap_k);
+                c->step_travel / std::sqrt(c->prm.search_radius_sq), c->in_travel / std::sqrt(c->prm.search_radius_sq), c->cap_k,
+                (unsigned long long)c->build_handed_on);
     if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
     return SPH_OK;
 }
@@ -1456,6 +1486,7 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     }
     if (const char* e = getenv("SPH_TRACE")) c->trace = atoi(e) != 0;
     if (const char* e = getenv("SPH_CHECK_LISTS")) c->check_lists = atoi(e) != 0;
+    if (const char* e = getenv("SPH_BUILD_TRIPS")) c->build_trips = (uint32_t)std::min<long>(BUILD_TRIPS, std::max<long>(0, atol(e)));
     if (const char* e = getenv("SPH_TWO_LEVEL_MIN_SKIN")) c->two_level_min_skin = atof(e);
     c->skin_k2_auto = getenv("SPH_SKIN_K2") == nullptr;
     if (const char* e = getenv("SPH_SKIN_K2")) c->skin_k2 = atof(e);

@@ -674,19 +674,24 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_draw_lists(const uint2* __restric
 #define BUILD_STAGE_STRIDE (2 * BUILD_RING + 4) /* two rings and a spare word per lane */
 typedef uint32_t u32x4_t_a16 __attribute__((ext_vector_type(4), aligned(16)));
 template <int DIM>
-__global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict__ rec, const uint2* __restrict__ qpos, uint32_t n,
+__global__ __launch_bounds__(SPH_BLOCK) void k_build_list_ring(const Rec* __restrict__ rec, const uint2* __restrict__ qpos, uint32_t n,
                                                           GridParams g,
                                                           const uint32_t* __restrict__ cstart, double rl2, uint32_t rl2q,
                                                           uint32_t* __restrict__ nbr, uint32_t stride, uint32_t cap,
                                                           uint32_t* __restrict__ cnt, uint32_t* __restrict__ need,
                                                           int prune_walls, const uint32_t* __restrict__ hstart,
                                                           uint32_t rin2q, uint32_t* __restrict__ nbr_in,
-                                                          uint32_t* __restrict__ cnt_in) {
+                                                          uint32_t* __restrict__ cnt_in, const uint32_t* __restrict__ todo,
+                                                          uint32_t todo_n) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[(SPH_BLOCK / 4) * BUILD_STAGE_STRIDE];
     const uint32_t q = threadIdx.x & 3u;
-    const uint32_t i_raw = xcd_contiguous_block() * (SPH_BLOCK / 4) + (threadIdx.x >> 2);
-    const bool active = i_raw < n;
-    const uint32_t i = active ? i_raw : n - 1;
+    /* todo != nullptr: the rows of the todo_n particles named there (those k_build_list handed on);
+     * otherwise the rows of all n particles */
+    const uint32_t slot = (todo ? blockIdx.x : xcd_contiguous_block()) * (SPH_BLOCK / 4) + (threadIdx.x >> 2);
+    const bool listed = todo ? slot < todo_n : slot < n;
+    const uint32_t i_named = todo ? todo[listed ? slot : 0u] : slot;
+    const bool active = listed && i_named < n;
+    const uint32_t i = active ? i_named : n - 1;
     const uint2 pi = qpos[i];
     /* prune_walls: pairs of two wall particles are left out (see k_walls_at_rest): or-ed into the
      * squared distance, a wall candidate's mark puts it beyond any radius */
@@ -834,6 +839,183 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
         cnt[i] = kc;
         if (k > cap) atomicMax(need, k);
         if (two) cnt_in[i] = kc_in;
+    }
+}
+
+/* The list build proper.  Same ranges, same tests and the same rows as k_build_list_ring above, but
+ * the keepers are not placed one by one while the ranges are walked (two thirds of that kernel's
+ * vector instructions: a rank, a ring slot and an LDS store per TESTED candidate and list, six out of
+ * seven of them thrown away).  Walking a range only RECORDS, per sixteen candidates with a keeper
+ * among them, where they start, the quad's two keep masks and how many keepers came before (12 bytes
+ * in LDS, written by one lane).  When all ranges are done the rows are written from the records: a
+ * lane takes a quarter of a row's groups of four, finds the record that holds its first keeper (a
+ * binary search over the running counts), and from there peels the set bits off the masks -- work per
+ * KEPT candidate -- into 16-byte stores.  Rows, counts and padding are exactly the ring kernel's.
+ *   A quad has room for `trips_max` records (at most BUILD_TRIPS).  A particle that needs more (far
+ * denser surroundings than the cells were sized for) is named in `todo` instead, counted in need[1],
+ * and the host has k_build_list_ring write its rows. */
+#define BUILD_TRIPS 40
+#define BUILD_REC_STRIDE (BUILD_TRIPS + 1)
+template <int DIM>
+__global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict__ rec, const uint2* __restrict__ qpos, uint32_t n,
+                                                          GridParams g,
+                                                          const uint32_t* __restrict__ cstart, double rl2, uint32_t rl2q,
+                                                          uint32_t* __restrict__ nbr, uint32_t stride, uint32_t cap,
+                                                          uint32_t* __restrict__ cnt, uint32_t* __restrict__ need,
+                                                          int prune_walls, const uint32_t* __restrict__ hstart,
+                                                          uint32_t rin2q, uint32_t* __restrict__ nbr_in,
+                                                          uint32_t* __restrict__ cnt_in, uint32_t trips_max,
+                                                          uint32_t* __restrict__ todo) {
+    __shared__ uint2 s_rec[(SPH_BLOCK / 4) * BUILD_REC_STRIDE];   /* first of the sixteen; masks: list | step list << 16 */
+    __shared__ uint32_t s_kb[(SPH_BLOCK / 4) * BUILD_REC_STRIDE]; /* keepers before the record, likewise packed */
+    const uint32_t q = threadIdx.x & 3u;
+    const uint32_t i_raw = xcd_contiguous_block() * (SPH_BLOCK / 4) + (threadIdx.x >> 2);
+    const bool active = i_raw < n;
+    const uint32_t i = active ? i_raw : n - 1;
+    const uint2 pi = qpos[i];
+    const uint32_t wall_mask = (prune_walls && (pi.y & QPOS_WALL)) ? QPOS_WALL : 0u;
+    const s16x2_t xyi = __builtin_bit_cast(s16x2_t, pi.x), zi = __builtin_bit_cast(s16x2_t, pi.y);
+    const double xi = rec[i].xv[0][0], yi = rec[i].xv[1][0], zi_d = DIM == 3 ? rec[i].xv[2][0] : 0.0;
+    const double run_i = DIM == 3 ? zi_d : yi;
+    const double edge_d = 1.0 / g.inv[0];
+    const int cx = cell_coord(xi, g.lo[0], g.inv[0], g.n[0]);
+    const int cy = DIM == 3 ? cell_coord(yi, g.lo[1], g.inv[1], g.n[1]) : 0;
+    const bool two = nbr_in != nullptr;
+    uint2* const myrec = s_rec + (threadIdx.x >> 2) * BUILD_REC_STRIDE;
+    uint32_t* const mykb = s_kb + (threadIdx.x >> 2) * BUILD_REC_STRIDE;
+    const double fx = fmin(fmax((xi - g.lo[0]) * g.inv[0] - (double)cx, 0.0), 1.0);
+    const double fy = DIM == 3 ? fmin(fmax((yi - g.lo[1]) * g.inv[1] - (double)cy, 0.0), 1.0) : 0.0;
+    const double reach2 = rl2 * g.inv[0] * g.inv[0] * (1.0 + 1e-6);
+    const uint32_t lim = trips_max < BUILD_TRIPS ? trips_max : BUILD_TRIPS;
+    uint32_t k = 0, k_in = 0; /* keepers so far */
+    uint32_t T = 0;           /* records so far, counted on when they no longer fit */
+    auto walk = [&](uint32_t b, uint32_t e, bool self_col) {
+        for (uint32_t j0 = b & ~1u; j0 < e; j0 += 16u) {
+            const uint32_t jl = j0 + 4u * q;
+            const u32x4_t_a16 A = *(const u32x4_t_a16*)(qpos + jl), B = *(const u32x4_t_a16*)(qpos + jl + 2u);
+            const uint32_t lo[4] = {A.x, A.z, B.x, B.z}, hi[4] = {A.y, A.w, B.y, B.w};
+            uint32_t nib = 0, nib_in = 0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const s16x2_t dxy = __builtin_bit_cast(s16x2_t, lo[m]) - xyi;
+                uint32_t d2 = (uint32_t)__builtin_amdgcn_sdot2(dxy, dxy, 0, false);
+                if (DIM == 3) {
+                    const uint32_t dzw = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2_t, hi[m]) - zi) & 0xFFFFu;
+                    const s16x2_t dz = __builtin_bit_cast(s16x2_t, dzw);
+                    d2 = (uint32_t)__builtin_amdgcn_sdot2(dz, dz, (int)d2, false);
+                }
+                d2 |= hi[m] & wall_mask;
+                nib |= d2 <= rl2q ? 1u << m : 0u;
+                nib_in |= d2 <= rin2q ? 1u << m : 0u;
+            }
+            const int room = (int)e - (int)jl;
+            uint32_t ok = room >= 4 ? 0xFu : (room > 0 ? (1u << room) - 1u : 0u);
+            if (jl < b) ok &= ~1u;
+            if (self_col) {
+                const uint32_t s = i - jl;
+                if (s < 4u) ok &= ~(1u << s);
+            }
+            if (!active) ok = 0;
+            nib &= ok;
+            nib_in &= nib;
+            uint32_t w = (nib | (nib_in << 16)) << (4u * q);
+            w |= (uint32_t)quad_perm_i<0xB1>((int)w);
+            w |= (uint32_t)quad_perm_i<0x4E>((int)w);
+            if (w != 0u) { /* the same in the quad's four lanes */
+                if (q == 0 && T < lim) {
+                    myrec[T] = make_uint2(j0, w);
+                    mykb[T] = (k < 0xFFFFu ? k : 0xFFFFu) | ((k_in < 0xFFFFu ? k_in : 0xFFFFu) << 16);
+                }
+                ++T;
+                k += __popc(w & 0xFFFFu);
+                k_in += __popc(w >> 16);
+            }
+        }
+    };
+    constexpr int NCOL = DIM == 3 ? 9 : 3;
+    uint32_t cb[NCOL], ce[NCOL], qb[NCOL], qe[NCOL];
+#pragma unroll
+    for (int t = 0; t < NCOL; ++t) {
+        const int dx = DIM == 3 ? t / 3 - 1 : t - 1, dy = DIM == 3 ? t % 3 - 1 : 0;
+        const int ax = cx + dx, ay = cy + dy;
+        const double gx = dx < 0 ? fx : (dx > 0 ? 1.0 - fx : 0.0);
+        const double gy = dy < 0 ? fy : (dy > 0 ? 1.0 - fy : 0.0);
+        const double gap2 = gx * gx + gy * gy;
+        const bool take = ax >= 0 && ax < g.n[0] && (DIM != 3 || (ay >= 0 && ay < g.n[1])) && !(gap2 > reach2);
+        const double hw = sqrt(fmax(reach2 - gap2, 0.0)) * edge_d * (1.0 + 1e-6) + 1e-9 * edge_d;
+        const uint32_t fa = (uint32_t)cell_coord(run_i - hw, g.lo[DIM - 1], g.invf, (int)g.nrun);
+        const uint32_t fb = (uint32_t)cell_coord(run_i + hw, g.lo[DIM - 1], g.invf, (int)g.nrun);
+        const uint32_t base = take ? column_index<DIM>(g, ax, ay) * g.nrun : 0u;
+        const uint32_t b0 = cstart[base + fa], e0 = cstart[base + fb + 1u];
+        cb[t] = take ? b0 : 0xFFFFFFFEu;
+        ce[t] = take ? e0 : 0u;
+        if (hstart) {
+            const uint32_t b1 = hstart[base + fa], e1 = hstart[base + fb + 1u];
+            qb[t] = take ? b1 : 0xFFFFFFFEu;
+            qe[t] = take ? e1 : 0u;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NCOL; ++t) {
+        walk(cb[t], ce[t], t == NCOL / 2);
+        if (hstart) walk(qb[t], qe[t], false);
+    }
+    if (T > lim) { /* no room for this particle's records: its rows are written by the other kernel */
+        if (active && q == 0) todo[atomicAdd(need + 1, 1u)] = i;
+    } else {
+        /* the rows from the records; sh: which half of the packed words */
+        auto expand = [&](uint32_t sh, uint32_t total, uint32_t* dst_row) {
+            const uint32_t kc = total < cap ? total : cap;
+            const uint32_t G = (kc + 3u) >> 2, Gq = (G + 3u) >> 2; /* groups of four: in the row, per lane */
+            const uint32_t g0 = q * Gq;
+            const uint32_t g1 = g0 + Gq < G ? g0 + Gq : G;
+            if (g0 < g1) { /* then kc > 0 and there is at least one record */
+                const uint32_t r0 = 4u * g0; /* the rank of this lane's first keeper */
+                uint32_t lo = 0, hi = T;
+#pragma unroll
+                for (int s = 0; s < 6; ++s) { /* the last record with no more than r0 keepers before it (2^6 > BUILD_TRIPS) */
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const bool le = ((mykb[mid] >> sh) & 0xFFFFu) <= r0;
+                    lo = le ? mid : lo;
+                    hi = le ? hi : mid;
+                }
+                uint32_t t = lo;
+                uint2 r = myrec[t];
+                uint32_t m = (r.y >> sh) & 0xFFFFu;
+                for (uint32_t d = r0 - ((mykb[t] >> sh) & 0xFFFFu); d > 0u && m != 0u; --d) m &= m - 1u;
+                for (uint32_t gq = g0; gq < g1; ++gq) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (uint32_t s = 0; s < 4u; ++s) {
+                        v[s] = i; /* the last group's padding */
+                        if (4u * gq + s < kc) {
+                            while (m == 0u && t + 1u < T) {
+                                ++t;
+                                r = myrec[t];
+                                m = (r.y >> sh) & 0xFFFFu;
+                            }
+                            const uint32_t bit = m != 0u ? (uint32_t)__builtin_ctz(m) : 0u;
+                            v[s] = r.x + bit;
+                            m &= m - 1u;
+                        }
+                    }
+                    if (4u * gq + 4u <= stride) {
+                        u32x4_t_a16 o;
+                        o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+                        *(u32x4_t_a16*)(dst_row + 4u * gq) = o;
+                    }
+                }
+            }
+        };
+        if (active) {
+            expand(0u, k, nbr + (size_t)i * stride);
+            if (two) expand(16u, k_in, nbr_in + (size_t)i * stride);
+            if (q == 0) {
+                cnt[i] = k < cap ? k : cap;
+                if (k > cap) atomicMax(need, k);
+                if (two) cnt_in[i] = k_in < cap ? k_in : cap;
+            }
+        }
     }
 }
 

@@ -399,6 +399,43 @@ def test_density_reinit_beyond_the_one_workgroup_size(spec):
     sim.close()
 
 
+@pytest.mark.parametrize("name", ["wcxsph3d_block", "wcxsph_fine", "droplet3d"])
+def test_list_build_from_records_and_by_the_ring_kernel_give_the_same_rows(name, monkeypatch, capfd):
+    # The list build records keep masks while it walks the cell ranges and writes the rows from the
+    # records; a particle whose records do not fit is handed to the kernel that places keepers in
+    # rings as it goes.  Three runs: as shipped (room for 40 records), room for one (most particles
+    # handed on), the ring kernel alone.  Rows feed the sums in their order, so every field must come
+    # out bit for bit, redone steps and list rebuilds included.
+    import re
+    spec = util.drop_cases()[name] if name in util.drop_cases() else util.small_cases()[name]
+    monkeypatch.setenv("SPH_TRACE", "1")
+    got = {}
+    for trips in ("40", "1", "0"):
+        monkeypatch.setenv("SPH_BUILD_TRIPS", trips)
+        _, pc = util.both_cases(spec)
+        sim = capi.Sim.from_case(pc)
+        sim.forces(capi.STATE_N)
+        sim.zero_boundary_forces(capi.STATE_N)
+        sc = sim.step(25)
+        offs, cols = sim.neighbours(capi.STATE_NP1)
+        st = sim.download(capi.STATE_NP1)
+        sim.density_reinit()
+        rho = sim.download(capi.STATE_NP1, names=("rho",))["rho"]
+        sim.close()
+        handed = [int(v) for v in re.findall(r"handed on (\d+)", capfd.readouterr().err)]
+        got[trips] = (st, offs, cols, rho, sc["list_rebuilds"], max(handed))
+    assert got["40"][5] == 0 and got["1"][5] > 0 and got["0"][5] == 0
+    assert got["40"][4] >= 2  # the lists were rebuilt along the way
+    want = got["0"]
+    for trips in ("40", "1"):
+        st, offs, cols, rho, rebuilds, _ = got[trips]
+        assert rebuilds == want[4]
+        assert np.array_equal(offs, want[1]) and np.array_equal(cols, want[2])
+        assert np.array_equal(rho.view(np.int32), want[3].view(np.int32))
+        for k, a in st.items():
+            assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(want[0][k]).view(np.uint8)), (trips, k)
+
+
 def test_density_reinit_in_one_launch_and_by_levels_give_the_same_bits(monkeypatch, capfd):
     # a single rank's large case is walked in one launch (every particle as soon as the neighbours
     # before it are done); slab runs walk level by level.  Same sums in the same order: same bits.
