@@ -141,7 +141,7 @@ struct sph_ctx {
     bool lost = false;           /* a launch of this context never came back: every later call fails at once, and
                                     sph_destroy frees nothing on the device (it would wait for that launch) */
     uint32_t ri_gen = 0;         /* its calls so far: the tag of the densities a call publishes */
-    double ri_limit_s = 10.0;    /* a wave of it gives up after waiting this long for one thing (a whole walk takes < 1 s) */
+    double ri_limit_s = 2.0;     /* a wave of it gives up after waiting this long for one thing (a whole walk takes < 1 s) */
     uint64_t reinit_launches = 0; /* of the last density re-initialisation: launches of its walk, */
     uint64_t reinit_rounds = 0;   /* exchange rounds (slab runs) */
     uint32_t reinit_walked = 0;   /* and how it walked (SPH_REINIT_*) */
