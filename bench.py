@@ -298,6 +298,8 @@ def main():
     ap.add_argument("--strong-fluid", type=str, default="",
                     help="fluid block of the strong-scaling leg (default 2048x1024x48, the >=100 M-particle case)")
     ap.add_argument("--strong-steps", type=int, default=10, help="timed steps of the strong-scaling leg")
+    ap.add_argument("--strong-child", action="store_true",
+                    help="internal: this process is one rank of the strong-scaling leg, started by a rank of the run proper")
     ap.add_argument("--skin", type=float, default=0.0, help="tuning: candidate-list skin fraction (0 = follow the motion)")
     ap.add_argument("--inner", type=float, default=0.0, help="tuning: step-list margin (0 = automatic, <0 = no step lists)")
     args = ap.parse_args()
@@ -326,6 +328,8 @@ def main():
     nx, ny, nz = (int(v) for v in args.fluid.lower().split("x"))
     if world > 1:
         from sph_amd import domain
+        if args.strong_child:
+            return domain.strong_child_main(args, world, rank, local_rank)
         return domain.bench_main(args, world, rank, local_rank, (nx, ny, nz))
 
     case = dam_break_3d(nx, ny, nz)

@@ -178,7 +178,9 @@ class SlabSim(capi.Sim):
         p.npts_global = p.npts
         p.npts = n
         p.rank, p.nranks = rank, nranks
-        room = halo_room if halo_room is not None else max(1 << 16, n // 8)
+        # a rank of up to 32 M particles gets room for half as many again to migrate in (a collapsing
+        # column fills the slabs ahead of it); a larger one a quarter, which still fits the GPU
+        room = halo_room if halo_room is not None else max(1 << 16, n // 4 if n <= (32 << 20) else n // 8)
         p.capacity = n + 4 * room  # growth by migration 2*room, each side's halo room
         p.migrate = 1 if migrate else 0
         big = 1e300
@@ -393,8 +395,7 @@ def bench_main(args, world, rank, local_rank, fluid):
     if not strong and not args.no_strong:
         sim.close()
         sim = None
-        strong_leg = strong_scaling_leg(args, world, rank, local_rank, transport, ident if transport == "rccl" else None,
-                                        sync, agree_max, all_ok_soft=lambda err: agree_max([1.0 if err else 0.0])[0] > 0)
+        strong_leg = strong_leg_in_children(args, world, rank, transport, dist)
 
     if rank == 0:
         per = [int(c[0]) for c in alli]
@@ -431,6 +432,112 @@ def bench_main(args, world, rank, local_rank, fluid):
     watchdog.cancel()
     if why_not_rccl:
         raise SystemExit(4)
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def strong_leg_in_children(args, world, rank, transport, dist):
+    """The strong-scaling leg runs in processes of its own, one started by every rank (the same
+    program with --strong-child, a rendezvous port of their own).  Whatever happens to them -- a
+    rank out of memory or of room for migrating particles, a communicator that never comes up --
+    the ranks of the run proper stay in step, wait at most SPH_STRONG_LIMIT_S seconds, and the
+    headline is printed with the leg's figures or with what went wrong.  Collective."""
+    import subprocess
+    import bench as B
+    port = [free_port() if rank == 0 else None]
+    dist.broadcast_object_list(port, src=0)
+    # the launcher's own rendezvous store (TORCHELASTIC_*) belongs to the run proper: the leg's ranks
+    # meet at a port of their own, rank 0 of them serving it
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(MASTER_PORT=str(port[0]), SPH_TRANSPORT=transport)
+    cmd = [sys.executable, os.path.abspath(B.__file__), "--strong-child", "--gpus", str(world), "--preroll", str(args.preroll),
+           "--warmup", str(args.warmup), "--strong-steps", str(args.strong_steps), "--skin", str(args.skin),
+           "--inner", str(args.inner), "--no-cpu"]
+    if args.strong_fluid:
+        cmd += ["--strong-fluid", args.strong_fluid]
+    limit_s = float(os.environ.get("SPH_STRONG_LIMIT_S", "600"))
+    err, text, child = None, "", None
+    try:
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    except OSError as e:
+        err = "rank %d could not start its process of the leg: %r" % (rank, e)
+    # the ranks look at their processes together twice a second: when one of them has failed (or
+    # time is up) the others' processes -- waiting for it in some exchange -- are stopped as well
+    RUNNING, DONE, FAILED = 0, 1, 2
+    t0 = time.perf_counter()
+    while True:
+        rc = child.poll() if child is not None else 1
+        mine = RUNNING if rc is None else (DONE if rc == 0 and err is None else FAILED)
+        if mine == FAILED and err is None:
+            err = "rank %d of the leg ended with code %d" % (rank, rc)
+        if mine == RUNNING and time.perf_counter() - t0 > limit_s:
+            mine, err = FAILED, "rank %d of the leg did not finish within %.0f s and was stopped" % (rank, limit_s)
+        states = [None] * world
+        dist.all_gather_object(states, mine)
+        if FAILED in states or all(v == DONE for v in states):
+            break
+        time.sleep(0.5)
+        if rank == 0 and int(time.perf_counter() - t0) // 60 != int(time.perf_counter() - t0 - 0.5) // 60:
+            print("strong-scaling leg: %.0f s so far" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
+    if child is not None:
+        if child.poll() is None:
+            child.kill()  # this very process, nothing else
+        text = child.communicate()[0].decode(errors="replace")
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    errs = [e for e in errs if e]
+    if errs:
+        return {"error": "; ".join(errs)}
+    if rank != 0:
+        return None
+    try:
+        return json.loads(text.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return {"error": "the leg printed no result line"}
+
+
+def strong_child_main(args, world, rank, local_rank):
+    """One rank of the strong-scaling leg (see strong_leg_in_children): rank 0 prints the leg's
+    figures as one JSON line; any failure ends the process with a non-zero code."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)  # gloo reports its connections on stdout
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    def agree_max(vals):
+        t = torch.tensor(vals, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    transport = os.environ.get("SPH_TRANSPORT", "rccl")
+    res = strong_scaling_leg(args, world, rank, local_rank, transport, None, sync, agree_max,
+                             all_ok_soft=lambda err: agree_max([1.0 if err else 0.0])[0] > 0)
+    failed = "error" in res
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if failed:
+        raise SystemExit(1)
 
 
 def single_gpu_anchor(fluid):

@@ -87,6 +87,27 @@ def test_two_rank_line(scaling, fluid):
         assert "strong" not in d["config"]
 
 
+@pytest.mark.parametrize("how", ["no such case", "out of time"])
+def test_a_failing_strong_leg_is_reported_inside_the_line(how):
+    # the strong-scaling leg runs in processes of its own: when it cannot be set up, or does not come
+    # back in time and is stopped, the headline is still printed, with what went wrong, and the run
+    # ends well
+    env = dict(os.environ, SPH_TRANSPORT="host")
+    extra = ["--fluid", "48x24x12", "--strong-steps", "2"]
+    if how == "out of time":
+        env["SPH_STRONG_LIMIT_S"] = "0.2"
+        extra += ["--strong-fluid", "96x24x12"]
+    else:
+        extra += ["--strong-fluid", "none"]  # every rank of the leg fails on it
+    r = _two_ranks(extra, env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = _check(lines[0], 2, 2, 1, "weak")
+    st = d["config"]["strong"]
+    assert "error" in st and ("did not finish" in st["error"]) == (how == "out of time"), st
+
+
 def test_more_ranks_than_gpus_are_refused_before_anything_runs():
     # RCCL refuses two ranks on one GPU: unless the host-staged transport is asked for, the run
     # says so and ends before a GPU is touched -- no line, a failure code
