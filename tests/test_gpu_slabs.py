@@ -346,12 +346,14 @@ def test_density_reinit_across_slabs(name, nranks, walk, tmp_path, monkeypatch):
     assert util.float_ulp_diff(res["step_rho"], o["rho"]).max() <= 1
 
 
-@pytest.mark.parametrize("walk", ["flow", "flow_together"])
-def test_density_reinit_across_slabs_with_particles_changing_owner(walk, tmp_path, monkeypatch):
-    # a droplet moving in x: particles cross the plane between the frames' re-initialisations
+@pytest.mark.parametrize("walk,transport", [("flow", "host"), ("flow_together", "host"), ("flow_together", "device"),
+                                            ("levels", "device")])
+def test_density_reinit_across_slabs_with_particles_changing_owner(walk, transport, tmp_path, monkeypatch):
+    # a droplet moving in x: particles cross the plane between the frames' re-initialisations;
+    # also over the device-buffer form of the callbacks, which is how the RCCL transport is driven
     choose_walk(monkeypatch, walk)
     spec = util.drop_cases()["droplet3d"]
-    res = run_slabs(spec, 2, tmp_path, steps=6, reinit=2, skin=0.05)
+    res = run_slabs(spec, 2, tmp_path, steps=6, reinit=2, skin=0.05, transport=transport)
     reinit_walk_ran(res, walk)
     oc, _ = util.both_cases(spec)
     orc = O.Oracle(oc)
