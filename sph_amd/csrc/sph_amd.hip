@@ -1111,9 +1111,13 @@ int draw_step_lists(sph_ctx* c, const Rec* r, bool entries_ready = false) {
         HIPCHK(hipEventRecord(ev->a, c->stream));
     }
     const QLattice& L = c->lattice;
-    /* entries_ready: the sweep that wrote these records left their lattice entries as well */
+    /* entries_ready: the sweep that wrote the owned particles' records left their lattice entries as
+     * well; the neighbours' particles (behind the owned ones) arrived as records only */
     if (!entries_ready)
         hipLaunchKernelGGL(k_fill_qpos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, r, m, L, c->dim, nullptr, 0u, qpos_of(c));
+    else if (c->n_halo)
+        hipLaunchKernelGGL(k_fill_qpos, dim3(nblk(c->n_halo)), dim3(SPH_BLOCK), 0, c->stream, r + c->n, c->n_halo, L, c->dim, nullptr,
+                           0u, qpos_of(c) + c->n);
     /* radius in lattice spacings, widened by the two spacings the rounding can cost */
     const double rq = std::sqrt(c->r_in2) * L.invq + 2.0;
     const uint32_t r2q = (uint32_t)std::ceil(rq * rq);
@@ -1188,11 +1192,11 @@ void fill_scalars(sph_ctx* c, sph_scalars* out) {
 int sweep_launches(sph_ctx* c, int cur, int nxt, bool last, bool commit, bool entries, uint32_t* part_n_out) {
     const uint32_t n = c->n;
     OutState o = out_state(c, SPH_STATE_NP1);
+    if (entries) { /* the draw that follows reads the new positions' lattice entries */
+        o.qpos = qpos_of(c);
+        o.lat = c->lattice;
+    }
     if (!c->dist) {
-        if (entries) { /* the draw that follows reads the new positions' lattice entries */
-            o.qpos = qpos_of(c);
-            o.lat = c->lattice;
-        }
         /* commit: the launch also writes state n (see k_pair, store_out == 2) */
         *part_n_out = pairgrid(n);
         return launch_sweep(c, c->rec[cur], c->rec[nxt], o, last ? (commit ? 2 : 1) : 0, 0, n, 0, *part_n_out);
@@ -1309,7 +1313,7 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             /* a single domain's last sweep commits the step itself; ranks first agree on whether
              * the step stands (below), and k_commit follows */
             const bool draw_next = two && k == 0 && !last;
-            CHK(sweep_launches(c, cur, nxt, last, last && !partial && !c->dist, draw_next && !c->dist, &part_n));
+            CHK(sweep_launches(c, cur, nxt, last, last && !partial && !c->dist, draw_next, &part_n));
             if (ev) HIPCHK(hipEventRecord(ev->b, c->stream));
             hipLaunchKernelGGL(k_fold_parts, dim3(PART_GROUPS, PART_FIELDS), dim3(SPH_BLOCK), 0, c->stream, c->part_use, part_n, PART_FIELDS,
                                c->part2_use);
@@ -1323,7 +1327,7 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             }
             hipLaunchKernelGGL(k_sweep_finalize, dim3(1), dim3(1), 0, c->stream, c->dp, c->S, c->part2_use, k,
                                (last && !partial) ? 1 : (last ? 2 : 0), cand_limit, (two && k >= 1) ? 1 : 0, 0);
-            if (draw_next) CHK(draw_step_lists(c, c->rec[nxt], !c->dist));
+            if (draw_next) CHK(draw_step_lists(c, c->rec[nxt], true));
             cur = nxt;
         }
         CommitArgs a;
