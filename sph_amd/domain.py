@@ -441,7 +441,7 @@ def free_port():
         return so.getsockname()[1]
 
 
-def strong_leg_in_children(args, world, rank, transport, dist):
+def strong_leg_in_children(args, world, rank, transport, dist, cmd=None):
     """The strong-scaling leg runs in processes of its own, one started by every rank (the same
     program with --strong-child, a rendezvous port of their own).  Whatever happens to them -- a
     rank out of memory or of room for migrating particles, a communicator that never comes up --
@@ -455,11 +455,12 @@ def strong_leg_in_children(args, world, rank, transport, dist):
     # meet at a port of their own, rank 0 of them serving it
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env.update(MASTER_PORT=str(port[0]), SPH_TRANSPORT=transport)
-    cmd = [sys.executable, os.path.abspath(B.__file__), "--strong-child", "--gpus", str(world), "--preroll", str(args.preroll),
-           "--warmup", str(args.warmup), "--strong-steps", str(args.strong_steps), "--skin", str(args.skin),
-           "--inner", str(args.inner), "--no-cpu"]
-    if args.strong_fluid:
-        cmd += ["--strong-fluid", args.strong_fluid]
+    if cmd is None:  # (tests of the watching give a command of their own)
+        cmd = [sys.executable, os.path.abspath(B.__file__), "--strong-child", "--gpus", str(world), "--preroll", str(args.preroll),
+               "--warmup", str(args.warmup), "--strong-steps", str(args.strong_steps), "--skin", str(args.skin),
+               "--inner", str(args.inner), "--no-cpu"]
+        if args.strong_fluid:
+            cmd += ["--strong-fluid", args.strong_fluid]
     limit_s = float(os.environ.get("SPH_STRONG_LIMIT_S", "600"))
     err, text, child = None, "", None
     try:

@@ -115,3 +115,64 @@ def test_host_transport_over_gloo(world):
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in results), results
+
+
+# ---- the bench's strong-scaling leg: processes of its own, watched by the ranks together --------
+
+_CHILD = """
+import os, sys, time
+rank, how = int(os.environ["RANK"]), sys.argv[1]
+assert "TORCHELASTIC_RUN_ID" not in os.environ and os.environ["SPH_TRANSPORT"] == "host"
+if how == "fine":
+    time.sleep(0.3 * rank)
+    if rank == 0:
+        print("noise on stdout")
+        print('{"value": 42.0, "port": %s}' % os.environ["MASTER_PORT"])
+elif how == "one fails":
+    if rank == 1:
+        sys.exit(3)
+    time.sleep(120)  # waits for the rank that is gone: must be stopped long before
+else:
+    time.sleep(120)
+"""
+
+
+def _leg_main(rank, world, port, how, q):
+    try:
+        import sys
+        import time
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          TORCHELASTIC_RUN_ID="the launcher's", SPH_STRONG_LIMIT_S="2")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t0 = time.perf_counter()
+        res = domain.strong_leg_in_children(None, world, rank, "host", dist, cmd=[sys.executable, "-c", _CHILD, how])
+        took = time.perf_counter() - t0
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, res, took))
+    except Exception as e:  # pragma: no cover - reported to the parent
+        import traceback
+        q.put((rank, traceback.format_exc() + repr(e), 0.0))
+
+
+@pytest.mark.parametrize("how", ["fine", "one fails", "all hang"])
+def test_strong_leg_processes_are_watched_and_stopped_together(how):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_leg_main, args=(r, 2, port, how, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    (_, res0, took0), (_, res1, took1) = results
+    assert max(took0, took1) < 30  # nobody sat out a process that waited for a dead one
+    if how == "fine":
+        assert res0["value"] == 42.0 and res0["port"] != port and res1 is None
+    else:
+        assert isinstance(res0, dict) and res0 == res1 and "error" in res0, results
+        assert ("ended with code 3" in res0["error"]) == (how == "one fails")
+        assert ("did not finish" in res0["error"]) == (how == "all hang")
