@@ -1037,10 +1037,10 @@ NState n_state(sph_ctx* c) {
     return s;
 }
 
-/* A step that a single domain's last sweep committed leaves f, V and Rrho of state n+1 only in
- * state n's arrays (pn = pnp1: the same values, written once).  Whoever is about to read state
- * n+1's arrays, or to change state n's, has them copied first.  The stepping path itself never
- * reads them. */
+/* A committed step leaves f, V, Rrho (and in a slab run p) of state n+1 only in state n's arrays
+ * (pn = pnp1: the same values, kept once -- see one_step).  Whoever is about to read state n+1's
+ * arrays, or to change state n's, has them copied first.  The stepping path itself never reads
+ * them (particles that migrate carry them along as they are, and the flag is the same on all ranks). */
 int settle_np1_outputs(sph_ctx* c) {
     if (!c->np1_out_in_n) return SPH_OK;
     const size_t n = c->n;
@@ -1049,6 +1049,7 @@ int settle_np1_outputs(sph_ctx* c) {
         if (c->xsph) HIPCHK(hipMemcpyAsync(c->pd[3 + d], c->nd[NVV(d)], n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
     HIPCHK(hipMemcpyAsync(c->pRrho, c->nfl[F_RRHO], n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->pp, c->nfl[F_P], n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     c->np1_out_in_n = false;
     return SPH_OK;
 }
@@ -1334,21 +1335,12 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
         memset(&a, 0, sizeof a);
         a.n = c->n;
         a.dim = c->dim;
-        a.xsph = c->xsph;
         a.rec = c->rec[cur];
         for (int d = 0; d < 3; ++d) {
-            a.pf[d] = c->pd[d];
-            a.pV[d] = c->pd[3 + d];
             a.nx[d] = c->nd[NX(d)];
             a.nv[d] = c->nd[NV(d)];
-            a.nV[d] = c->nd[NVV(d)];
-            a.nf[d] = c->nd[NF(d)];
         }
-        a.pRrho = c->pRrho;
-        a.pp = c->pp;
         a.nrho = c->nfl[F_RHO];
-        a.np = c->nfl[F_P];
-        a.nRrho = c->nfl[F_RRHO];
         if (c->dist) {
             /* the ranks agree on the maxima, the sums and on whether to redo the step -- one
              * exchange, on the device, in stream order; the time step and the commit follow
@@ -1381,8 +1373,19 @@ int one_step(sph_ctx* c, int nsweeps, bool partial) {
             ++c->redos;
             continue;
         }
-        /* the last sweep wrote f, V, Rrho: as state n's when it committed the step, else as state n+1's */
-        c->np1_out_in_n = !partial && !c->dist;
+        /* The last sweep wrote f, V, Rrho (and p): as state n's when it committed the step (a single
+         * domain).  A slab run's sweep wrote them as state n+1's and the step stands: they become
+         * state n's by changing places with the arrays that held state n's (which k_commit did not
+         * touch); either way state n+1's arrays are now the ones to be filled on demand. */
+        if (!partial && c->dist) {
+            for (int d = 0; d < c->dim; ++d) {
+                std::swap(c->pd[d], c->nd[NF(d)]);
+                std::swap(c->pd[3 + d], c->nd[NVV(d)]);
+            }
+            std::swap(c->pRrho, c->nfl[F_RRHO]);
+            std::swap(c->pp, c->nfl[F_P]);
+        }
+        c->np1_out_in_n = !partial;
         if (!partial) {
             /* mode 2 restarts the bound at every sweep; what it saw is a lower bound then */
             const double seen = c->disp_host - disp_at_start;
@@ -1558,11 +1561,11 @@ int sph_create(const sph_params* p, sph_ctx** out) {
             CHK(dalloc(c, &c->pd_alt[q * 3 + k], n));
             HIPCHK(hipMemsetAsync(c->pd[q * 3 + k], 0, n * sizeof(double), c->stream));
         }
-    CHK(dalloc(c, &c->pRrho, n));
-    CHK(dalloc(c, &c->pRrho_alt, n));
+    CHK(dalloc(c, &c->pRrho, n + (n & 1))); /* as long as state n's float arrays: they change places with them */
+    CHK(dalloc(c, &c->pRrho_alt, n + (n & 1)));
     HIPCHK(hipMemsetAsync(c->pRrho, 0, n * sizeof(float), c->stream));
-    CHK(dalloc(c, &c->pp, n));
-    CHK(dalloc(c, &c->pp_alt, n));
+    CHK(dalloc(c, &c->pp, n + (n & 1)));
+    CHK(dalloc(c, &c->pp_alt, n + (n & 1)));
     HIPCHK(hipMemsetAsync(c->pp, 0, n * sizeof(float), c->stream));
     CHK(dalloc(c, &c->id, n));
     CHK(dalloc(c, &c->id_alt, n));
@@ -2214,6 +2217,7 @@ int sph_density_reinit(sph_ctx* c) {
     if (!c) return SPH_EINVAL;
     if (!c->uploaded_np1) return fail(c, SPH_ESTATE, "state was never uploaded");
     HIPCHK(hipSetDevice(c->device));
+    CHK(settle_np1_outputs(c)); /* p of state n+1 is read below */
     if (!c->ri_pend) {
         CHK(dalloc(c, &c->ri_pend, c->cap));
         /* three frontier queues used in turn (walk by levels); the one-launch walk keeps its

@@ -1657,22 +1657,17 @@ __global__ void k_sweep_finalize(DevParams P, DevScalars* S, const double* __res
     }
 }
 
-/* pn = pnp1 and t += dt (WCXSPH3D.cpp:301-302), skipped when the step has to be redone. */
+/* pn = pnp1 and t += dt (WCXSPH3D.cpp:301-302), skipped when the step has to be redone.  Slab
+ * runs (a single domain's last sweep writes state n itself): x, v and rho from the records; f, V,
+ * Rrho and p become state n's by the host exchanging the arrays once it has seen that the step
+ * stands. */
 struct CommitArgs {
     uint32_t n;
-    int dim, xsph;
+    int dim;
     const Rec* rec;
-    const float* pp;
-    const double* pf[3];
-    const double* pV[3];
-    const float* pRrho;
     double* nx[3];
     double* nv[3];
-    double* nV[3];
-    double* nf[3];
     float* nrho;
-    float* np;
-    float* nRrho;
 };
 
 __global__ __launch_bounds__(SPH_BLOCK) void k_commit(CommitArgs a, DevScalars* S) {
@@ -1683,12 +1678,8 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_commit(CommitArgs a, DevScalars* 
     for (int d = 0; d < a.dim; ++d) {
         a.nx[d][i] = r.xv[d][0];
         a.nv[d][i] = r.xv[d][1];
-        a.nf[d][i] = a.pf[d][i];
-        if (a.xsph) a.nV[d][i] = a.pV[d][i];
     }
     a.nrho[i] = r.rho;
-    a.np[i] = a.pp[i];
-    a.nRrho[i] = a.pRrho[i];
 }
 
 __global__ void k_commit_scalars(DevScalars* S) {

@@ -101,6 +101,12 @@ def main():
     st = sim.download(capi.STATE_N)
     if args.reinit:
         st["np1_rho"] = sim.download(capi.STATE_NP1, names=("rho",))["rho"]
+    else:
+        # a step ends with pn = pnp1 (WCXSPH3D.cpp:301): every field of the two states, bit for bit
+        st1 = sim.download(capi.STATE_NP1)
+        for k in ("x", "v", "f", "V", "rho", "p", "Rrho"):
+            a, b = np.ascontiguousarray(st[k]), np.ascontiguousarray(st1[k])
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), "rank %d: state n+1 differs from state n in %s" % (rank, k)
     g1 = domain.gather_state(sim, st, dist)
     if rank == 0:
         for k, a in g0.items():
