@@ -200,8 +200,9 @@ int sph_profile_read_comm(sph_ctx* ctx, double* ms4, uint64_t* count4);
 /* How the last sph_density_reinit went through the particles (no counterpart in the reference,
  * whose DensityReinit is one loop in index order, WCXSPH3D.cpp:205-252; every way below gives that
  * loop's values): [0] one of SPH_REINIT_*, [1] launches of the walk's kernels, [2] slab runs: the
- * rounds of exchanges with the neighbouring ranks, [3] 1 when the ranks walked one after the other
- * because they share a GPU.  The array has four entries. */
+ * rounds of exchanges with the neighbouring ranks, [3] bit 0: the ranks walked one after the other
+ * because they share a GPU; bit 1: the call needed no list rebuild (the stepping path's lists stood, and
+ * the walk's lists were made on their order).  The array has four entries. */
 #define SPH_REINIT_NONE 0
 #define SPH_REINIT_ONE_WORKGROUP 1      /* small cases: one workgroup, a barrier per dependency level */
 #define SPH_REINIT_LEVELS 2             /* one launch per dependency level */

@@ -410,10 +410,12 @@ class Sim:
         self._chk(lib().sph_density_reinit(self._h), "sph_density_reinit")
 
     def reinit_info(self):
-        """How the last density_reinit() walked: dict(walk=one of REINIT_*, launches, rounds, took_turns)."""
+        """How the last density_reinit() walked: dict(walk=one of REINIT_*, launches, rounds, took_turns,
+        standing_lists: no list rebuild was needed)."""
         out = (C.c_uint64 * 4)()
         self._chk(lib().sph_reinit_info(self._h, out), "sph_reinit_info")
-        return dict(walk=int(out[0]), launches=int(out[1]), rounds=int(out[2]), took_turns=bool(out[3]))
+        return dict(walk=int(out[0]), launches=int(out[1]), rounds=int(out[2]), took_turns=bool(out[3] & 1),
+                    standing_lists=bool(out[3] & 2))
 
     def neighbours(self, which):
         offs = np.zeros(self.npts + 1, np.uint64)

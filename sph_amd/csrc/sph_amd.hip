@@ -136,6 +136,11 @@ struct sph_ctx {
     ReinitCtl* ri_ctl = nullptr;
     uint32_t* ri_flow = nullptr; /* control words of the one-launch walk */
     uint32_t ri_owners = 0;      /* its workgroups (all resident at once); 0 = walk by levels */
+    const uint32_t* ri_nbr = nullptr; /* the lists the walk reads: the candidate lists of a rebuild of its own, or rows */
+    const uint32_t* ri_cnt = nullptr; /* built for it on the standing order (reinit_lists_on_standing_order) */
+    bool ri_fresh_lists = false;      /* SPH_REINIT_LISTS=fresh: always rebuild */
+    bool probe_standing = false;      /* SPH_NEIGHBOURS_LISTS=standing: sph_neighbours reads lists made the same way */
+    uint64_t ri_quick_lists = 0;      /* calls served without a rebuild */
     size_t ri_gran_off = 0;      /* where the one-launch walk's published words began at the last call */
     bool ri_take_turns = false;  /* slab run, ranks sharing a GPU: the one-launch walks run one rank at a time */
     bool lost = false;           /* a launch of this context never came back: every later call fails at once, and
@@ -335,9 +340,71 @@ inline uint2* qpos_of(sph_ctx* c) { return (uint2*)((char*)c->rec_alt + (size_t)
 
 int ensure_step_lists(sph_ctx* c, bool* ok);
 
+/* One run of the list build over the cell table as it stands: the rows of every owned particle
+ * into `rows`/`counts` and, when `tin` is given, the entries within the second radius into
+ * `tin`/`tcnt` as well.  range2: the squared distance the cell ranges are chosen for; rl2q, rin2q:
+ * the two radii squared in lattice spacings.  *need_out: the longest row asked for (more than the
+ * rows hold: the caller grows them and builds again).  The lattice entries must be in place. */
+int run_list_build(sph_ctx* c, const Rec* r, double range2, uint32_t rl2q, uint32_t* rows, uint32_t* counts, int prune_walls,
+                   uint32_t rin2q, uint32_t* tin, uint32_t* tcnt, uint32_t* need_out, int stale_cells = 0) {
+    const uint32_t* hb = c->n_halo ? c->hbeg : nullptr;
+    HIPCHK(hipMemsetAsync(c->need, 0, 2 * sizeof(uint32_t), c->stream));
+    /* the particles whose records do not fit the build's LDS are named here for the ring kernel */
+    uint32_t* const todo = (uint32_t*)c->tmp;
+    /* the ring kernel over the `count` particles of `list` (nullptr: all of them) */
+    auto ring = [&](const uint32_t* list, uint32_t count) {
+        const dim3 grid(list ? (count + PAIR_PARTICLES - 1) / PAIR_PARTICLES : pairblocks(c->n));
+        if (c->dim == 3)
+            hipLaunchKernelGGL(k_build_list_ring<3>, grid, dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid, c->cbeg, range2,
+                               rl2q, rows, c->cap_k, c->cap_k, counts, c->need, prune_walls, hb, rin2q, tin, tcnt, list, count, stale_cells);
+        else
+            hipLaunchKernelGGL(k_build_list_ring<2>, grid, dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid, c->cbeg, range2,
+                               rl2q, rows, c->cap_k, c->cap_k, counts, c->need, prune_walls, hb, rin2q, tin, tcnt, list, count, stale_cells);
+    };
+    if (c->build_trips == 0) {
+        ring(nullptr, 0u);
+    } else if (c->dim == 3) {
+        hipLaunchKernelGGL(k_build_list<3>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid, c->cbeg,
+                           range2, rl2q, rows, c->cap_k, c->cap_k, counts, c->need, prune_walls, hb, rin2q, tin, tcnt, c->build_trips,
+                           todo, stale_cells);
+    } else {
+        hipLaunchKernelGGL(k_build_list<2>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid, c->cbeg,
+                           range2, rl2q, rows, c->cap_k, c->cap_k, counts, c->need, prune_walls, hb, rin2q, tin, tcnt, c->build_trips,
+                           todo, stale_cells);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->need_host, c->need, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->need_host[1] > 0) {
+        const uint32_t handed_on = c->need_host[1];
+        if (handed_on > c->n) return fail(c, SPH_ESTATE, "list build: more particles handed on than there are");
+        c->build_handed_on += handed_on;
+        ring(todo, handed_on);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    *need_out = *c->need_host;
+    return SPH_OK;
+}
+
+/* development check (SPH_CHECK_LISTS): every word of every row names a particle slot */
+int check_rows(sph_ctx* c, const uint32_t* rows, const uint32_t* counts, const uint32_t* tin, const uint32_t* tcnt) {
+    if (!c->check_lists) return SPH_OK;
+    uint32_t* bad = (uint32_t*)c->tmp;
+    HIPCHK(hipMemsetAsync(bad, 0, sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_check_lists, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, rows, c->cap_k, c->cap_k, counts, c->n, c->cap, bad);
+    if (tin)
+        hipLaunchKernelGGL(k_check_lists, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, tin, c->cap_k, c->cap_k, tcnt, c->n, c->cap, bad);
+    uint32_t h = 0;
+    HIPCHK(hipMemcpyAsync(&h, bad, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (h) return fail(c, SPH_ESTATE, "list check: a row names a slot beyond the arrays or holds too many entries");
+    return SPH_OK;
+}
+
 /* with_step_lists: the build writes the step lists too (radius r_in2), on the same positions */
 int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below, bool with_step_lists) {
-    const uint32_t* hb = c->n_halo ? c->hbeg : nullptr;
     /* lattice entries and wall marks of the owned and the neighbours' particles (in the spare
      * record array, which nothing else uses between a reorder and the next one) */
     const uint32_t m = c->n + c->n_halo;
@@ -349,67 +416,15 @@ int build_lists(sph_ctx* c, const Rec* r, uint32_t wall_below, bool with_step_li
     const uint32_t rl2q = (uint32_t)std::ceil(rlq * rlq), rin2q = (uint32_t)std::ceil(rinq * rinq);
     if (c->cap_k & 3u) return fail(c, SPH_ESTATE, "list rows must hold a multiple of four entries");
     for (int attempt = 0; attempt < 4; ++attempt) {
-        HIPCHK(hipMemsetAsync(c->need, 0, 2 * sizeof(uint32_t), c->stream));
         if (with_step_lists) { /* as many rows again, of the same length */
             bool ok = true;
             CHK(ensure_step_lists(c, &ok));
         }
         uint32_t* const tin = with_step_lists ? c->nbr_in : nullptr;
         uint32_t* const tcnt = with_step_lists ? c->cnt_in : nullptr;
-        /* the particles whose records do not fit the build's LDS are named here for the ring kernel */
-        uint32_t* const todo = (uint32_t*)c->tmp;
-        /* the ring kernel over the `count` particles of `list` (nullptr: all of them) */
-        auto ring = [&](const uint32_t* list, uint32_t count) {
-            const dim3 grid(list ? (count + PAIR_PARTICLES - 1) / PAIR_PARTICLES : pairblocks(c->n));
-            if (c->dim == 3)
-                hipLaunchKernelGGL(k_build_list_ring<3>, grid, dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid, c->cbeg,
-                                   c->r_list2, rl2q, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, rin2q, tin,
-                                   tcnt, list, count);
-            else
-                hipLaunchKernelGGL(k_build_list_ring<2>, grid, dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid, c->cbeg,
-                                   c->r_list2, rl2q, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, rin2q, tin,
-                                   tcnt, list, count);
-        };
-        if (c->build_trips == 0) {
-            ring(nullptr, 0u);
-        } else if (c->dim == 3) {
-            hipLaunchKernelGGL(k_build_list<3>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid,
-                               c->cbeg, c->r_list2, rl2q, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, rin2q,
-                               tin, tcnt, c->build_trips, todo);
-        } else {
-            hipLaunchKernelGGL(k_build_list<2>, dim3(pairblocks(c->n)), dim3(SPH_BLOCK), 0, c->stream, r, qpos_of(c), c->n, c->grid,
-                               c->cbeg, c->r_list2, rl2q, c->nbr, c->cap_k, c->cap_k, c->cnt, c->need, wall_below ? 1 : 0, hb, rin2q,
-                               tin, tcnt, c->build_trips, todo);
-        }
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(c->need_host, c->need, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->need_host[1] > 0) {
-            const uint32_t handed_on = c->need_host[1];
-            if (handed_on > c->n) return fail(c, SPH_ESTATE, "list build: more particles handed on than there are");
-            c->build_handed_on += handed_on;
-            ring(todo, handed_on);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(c->need_host, c->need, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-        }
-        const uint32_t need = *c->need_host;
-        if (need <= c->cap_k) {
-            if (c->check_lists) { /* development check: every word of every row names a particle slot */
-                uint32_t* bad = (uint32_t*)c->tmp;
-                HIPCHK(hipMemsetAsync(bad, 0, sizeof(uint32_t), c->stream));
-                hipLaunchKernelGGL(k_check_lists, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, c->nbr, c->cap_k, c->cap_k, c->cnt,
-                                   c->n, c->cap, bad);
-                if (tin)
-                    hipLaunchKernelGGL(k_check_lists, dim3(nblk(c->n)), dim3(SPH_BLOCK), 0, c->stream, tin, c->cap_k, c->cap_k, tcnt,
-                                       c->n, c->cap, bad);
-                uint32_t h = 0;
-                HIPCHK(hipMemcpyAsync(&h, bad, sizeof h, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(hipStreamSynchronize(c->stream));
-                if (h) return fail(c, SPH_ESTATE, "list check: a row names a slot beyond the arrays or holds too many entries");
-            }
-            return SPH_OK;
-        }
+        uint32_t need = 0;
+        CHK(run_list_build(c, r, c->r_list2, rl2q, c->nbr, c->cnt, wall_below ? 1 : 0, rin2q, tin, tcnt, &need));
+        if (need <= c->cap_k) return check_rows(c, c->nbr, c->cnt, tin, tcnt);
         /* some particle has more candidates than the lists hold: grow and build again */
         /* rows of whole 128-byte lines: a stride that is not a multiple of 64 bytes makes every
          * 16-entry group of a row straddle two lines (measured: a third more HBM reads in the pair
@@ -1493,6 +1508,8 @@ int sph_create(const sph_params* p, sph_ctx** out) {
     }
     if (const char* e = getenv("SPH_TRACE")) c->trace = atoi(e) != 0;
     if (const char* e = getenv("SPH_CHECK_LISTS")) c->check_lists = atoi(e) != 0;
+    if (const char* e = getenv("SPH_REINIT_LISTS")) c->ri_fresh_lists = !strcmp(e, "fresh");
+    if (const char* e = getenv("SPH_NEIGHBOURS_LISTS")) c->probe_standing = !strcmp(e, "standing");
     if (const char* e = getenv("SPH_BUILD_TRIPS")) c->build_trips = (uint32_t)std::min<long>(BUILD_TRIPS, std::max<long>(0, atol(e)));
     if (const char* e = getenv("SPH_TWO_LEVEL_MIN_SKIN")) c->two_level_min_skin = atof(e);
     c->skin_k2_auto = getenv("SPH_SKIN_K2") == nullptr;
@@ -1935,6 +1952,56 @@ int sph_set_dt(sph_ctx* c, double dt) {
 
 namespace {
 
+/* DensityReinit's lists without a list rebuild.  While the stepping path's lists stand, the
+ * particles are still in the order and in the cell table of the last rebuild, and none has
+ * travelled further than the bound kept for those lists.  A particle's neighbours within r now were
+ * therefore within r + travel of where it is now when the cells were filled: the build walks the
+ * cell ranges chosen for that distance and tests the candidates on their positions of now (fresh
+ * lattice entries), wall-wall pairs included.  The rows go where the step lists live (those are
+ * drawn afresh at the start of the next step, which costs a draw instead of the rebuild that a
+ * re-sorted order would force on it); the candidate lists, the order and the travel bound of the
+ * stepping path are left as they are.  *done stays false when this cannot be had (no standing
+ * lists, travel beyond what one cell's width covers, rows too short). */
+int reinit_lists_on_standing_order(sph_ctx* c, bool* done) {
+    *done = false;
+    if (c->ri_fresh_lists || !c->list_valid || !c->lists_for_step) {
+        if (c->trace) fprintf(stderr, "[sph] reinit: no lists on the standing order: asked for fresh ones %d, lists stand %d, made for stepping %d\n",
+                              (int)c->ri_fresh_lists, (int)c->list_valid, (int)c->lists_for_step);
+        return SPH_OK;
+    }
+    const double R = std::sqrt(c->prm.search_radius_sq);
+    double skin = 0.01;
+    if (const char* e = getenv("SPH_ONESHOT_SKIN")) skin = std::max(0.0, atof(e));
+    const double r = R * (1.0 + skin);
+    const double range = r + c->disp_host * (1.0 + 1e-9) + 1e-12 * R;
+    /* the neighbouring columns are all the build looks at: the range must not exceed a cell's edge */
+    if (!(c->disp_host >= 0.0) || !(range * (1.0 + 1e-6) <= 1.0 / c->grid.inv[0])) {
+        if (c->trace) fprintf(stderr, "[sph] reinit: no lists on the standing order: range %.4g, cell edge %.4g\n", range, 1.0 / c->grid.inv[0]);
+        return SPH_OK;
+    }
+    bool ok = true;
+    CHK(ensure_step_lists(c, &ok));
+    const Rec* rec = c->rec[c->b0];
+    const uint32_t m = c->n + c->n_halo;
+    const QLattice& L = c->lattice;
+    hipLaunchKernelGGL(k_fill_qpos, dim3(nblk(m)), dim3(SPH_BLOCK), 0, c->stream, rec, m, L, c->dim, nullptr, 0u, qpos_of(c));
+    const double rq = r * L.invq + 2.0;
+    const uint32_t r2q = (uint32_t)std::ceil(rq * rq);
+    uint32_t need = 0;
+    CHK(run_list_build(c, rec, range * range, r2q, c->nbr_in, c->cnt_in, 0, 0u, nullptr, nullptr, &need, 1));
+    c->step_lists_valid = false; /* their rows have just been used for something else */
+    if (need > c->cap_k) {
+        if (c->trace) fprintf(stderr, "[sph] reinit: no lists on the standing order: a row of %u entries, rows hold %u\n", need, c->cap_k);
+        return SPH_OK;
+    }
+    CHK(check_rows(c, c->nbr_in, c->cnt_in, nullptr, nullptr));
+    c->ri_nbr = c->nbr_in;
+    c->ri_cnt = c->cnt_in;
+    ++c->ri_quick_lists;
+    *done = true;
+    return SPH_OK;
+}
+
 /* One launch of the one-launch walk (or one round of it, in a slab run) and the wait for it.  The
  * waves give up by themselves after the context's time limit; should the launch outlive that by
  * far, the host raises the stop flag from a second stream, and if even that does not end it the
@@ -1945,11 +2012,11 @@ int reinit_flow_launch(sph_ctx* c, Rec* r, const uint32_t* ids, uint32_t owners,
     const uint64_t limit = (uint64_t)(c->ri_limit_s * 1e8); /* ticks of the 100 MHz clock */
     uint32_t* const h = (uint32_t*)c->need_host; /* pinned */
     if (c->dim == 3)
-        hipLaunchKernelGGL(k_reinit_flow<3>, dim3(owners), dim3(REINIT_FLOW_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
-                           c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, qseg, limit, gran, c->ri_gen, partial);
+        hipLaunchKernelGGL(k_reinit_flow<3>, dim3(owners), dim3(REINIT_FLOW_THREADS), 0, c->stream, c->dp, r, c->ri_nbr, c->cap_k,
+                           c->ri_cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, qseg, limit, gran, c->ri_gen, partial);
     else
-        hipLaunchKernelGGL(k_reinit_flow<2>, dim3(owners), dim3(REINIT_FLOW_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
-                           c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, qseg, limit, gran, c->ri_gen, partial);
+        hipLaunchKernelGGL(k_reinit_flow<2>, dim3(owners), dim3(REINIT_FLOW_THREADS), 0, c->stream, c->dp, r, c->ri_nbr, c->cap_k,
+                           c->ri_cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, qseg, limit, gran, c->ri_gen, partial);
     HIPCHK(hipGetLastError());
     ++c->reinit_launches;
     HIPCHK(hipMemcpyAsync(h, c->ri_flow, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1996,9 +2063,9 @@ int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
 #define RI_LEVEL()                                                                                                        \
     do {                                                                                                                  \
         if (c->dim == 3) hipLaunchKernelGGL(k_reinit_level<3>, dim3(grid), dim3(REINIT_LEVEL_THREADS), 0, c->stream, c->dp, r, \
-                                            c->nbr, c->cap_k, c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, qcap, level); \
-        else hipLaunchKernelGGL(k_reinit_level<2>, dim3(grid), dim3(REINIT_LEVEL_THREADS), 0, c->stream, c->dp, r, c->nbr,    \
-                                c->cap_k, c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, qcap, level);                     \
+                                            c->ri_nbr, c->cap_k, c->ri_cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, qcap, level); \
+        else hipLaunchKernelGGL(k_reinit_level<2>, dim3(grid), dim3(REINIT_LEVEL_THREADS), 0, c->stream, c->dp, r, c->ri_nbr,    \
+                                c->cap_k, c->ri_cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, qcap, level);                     \
         ++level;                                                                                                          \
     } while (0)
     uint32_t* touches = c->dist ? c->flags : nullptr;
@@ -2020,10 +2087,10 @@ int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
         HIPCHK(hipMemsetAsync(c->ri_flow, 0, sizeof(uint32_t) * REINIT_FLOW_WORDS(owners), c->stream));
     }
     if (c->dim == 3)
-        hipLaunchKernelGGL(k_reinit_count<3>, dim3((n + SPH_BLOCK / 4 - 1) / (SPH_BLOCK / 4)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k, c->cnt,
+        hipLaunchKernelGGL(k_reinit_count<3>, dim3((n + SPH_BLOCK / 4 - 1) / (SPH_BLOCK / 4)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->ri_nbr, c->cap_k, c->ri_cnt,
                            ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches, owners, qseg, c->ri_flow);
     else
-        hipLaunchKernelGGL(k_reinit_count<2>, dim3((n + SPH_BLOCK / 4 - 1) / (SPH_BLOCK / 4)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k, c->cnt,
+        hipLaunchKernelGGL(k_reinit_count<2>, dim3((n + SPH_BLOCK / 4 - 1) / (SPH_BLOCK / 4)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->ri_nbr, c->cap_k, c->ri_cnt,
                            ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches, owners, qseg, c->ri_flow);
     HIPCHK(hipGetLastError());
     ReinitCtl* h = (ReinitCtl*)c->need_host; /* pinned, 8 words */
@@ -2087,11 +2154,11 @@ int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
                 hipLaunchKernelGGL(k_reinit_unpack_flow, dim3(nblk(c->nrecv[1])), dim3(SPH_BLOCK), 0, c->stream, rb + hc,
                                    c->halo_pos + c->nrecv[0], c->nrecv[1], r, gran, c->ri_gen);
             if (c->dim == 3)
-                hipLaunchKernelGGL(k_reinit_rescan_flow<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
-                                   c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, touches, gran, c->ri_gen, owners, qseg);
+                hipLaunchKernelGGL(k_reinit_rescan_flow<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->ri_nbr, c->cap_k,
+                                   c->ri_cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, touches, gran, c->ri_gen, owners, qseg);
             else
-                hipLaunchKernelGGL(k_reinit_rescan_flow<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
-                                   c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, touches, gran, c->ri_gen, owners, qseg);
+                hipLaunchKernelGGL(k_reinit_rescan_flow<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->ri_nbr, c->cap_k,
+                                   c->ri_cnt, ids, c->ri_pend, c->ri_queue, c->ri_flow, touches, gran, c->ri_gen, owners, qseg);
             HIPCHK(hipGetLastError());
             uint64_t pushed_after = 0, done_same = 0;
             CHK(read_counts(&pushed_after, &done_same));
@@ -2152,11 +2219,11 @@ int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
                                    c->halo_pos + c->nrecv[0], c->nrecv[1], r, c->ri_pend);
             /* those set free by the neighbours' news join the frontier of the next level */
             if (c->dim == 3)
-                hipLaunchKernelGGL(k_reinit_rescan<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
-                                   c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches, qcap, level);
+                hipLaunchKernelGGL(k_reinit_rescan<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->ri_nbr, c->cap_k,
+                                   c->ri_cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches, qcap, level);
             else
-                hipLaunchKernelGGL(k_reinit_rescan<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
-                                   c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches, qcap, level);
+                hipLaunchKernelGGL(k_reinit_rescan<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, r, c->ri_nbr, c->cap_k,
+                                   c->ri_cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl, touches, qcap, level);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -2171,11 +2238,11 @@ int reinit_walk(sph_ctx* c, bool one_launch, bool* stalled) {
     } else if (n <= REINIT_SINGLE_MAX) { /* a small case is walked by one workgroup, level after level */
         ++c->reinit_launches;
         if (c->dim == 3)
-            hipLaunchKernelGGL(k_reinit_single<3>, dim3(1), dim3(REINIT_SINGLE_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
-                               c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl);
+            hipLaunchKernelGGL(k_reinit_single<3>, dim3(1), dim3(REINIT_SINGLE_THREADS), 0, c->stream, c->dp, r, c->ri_nbr, c->cap_k,
+                               c->ri_cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl);
         else
-            hipLaunchKernelGGL(k_reinit_single<2>, dim3(1), dim3(REINIT_SINGLE_THREADS), 0, c->stream, c->dp, r, c->nbr, c->cap_k,
-                               c->cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl);
+            hipLaunchKernelGGL(k_reinit_single<2>, dim3(1), dim3(REINIT_SINGLE_THREADS), 0, c->stream, c->dp, r, c->ri_nbr, c->cap_k,
+                               c->ri_cnt, ids, c->ri_pend, c->ri_queue, c->ri_ctl);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h, c->ri_ctl, sizeof(ReinitCtl), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -2265,9 +2332,21 @@ int sph_density_reinit(sph_ctx* c) {
                                   c->ri_owners ? "one-launch walk in rounds" : "walk by levels", c->ri_take_turns ? ", one rank at a time" : "");
         }
     }
-    /* complete lists (wall-wall pairs included) on the positions of state n+1; a slab run
-     * fetches its neighbours' particles with them */
-    CHK(rebuild(c, c->b0));
+    /* complete lists (wall-wall pairs included) on the positions of state n+1: on the standing
+     * order when the stepping path's lists stand, else by a rebuild (a slab run fetches its
+     * neighbours' particles with it) */
+    bool quick = false;
+    CHK(reinit_lists_on_standing_order(c, &quick));
+    if (c->dist) { /* all ranks walk the same lists */
+        double v[1] = {quick ? 0.0 : 1.0};
+        CHK(allreduce_host(c, v, 1, 0));
+        quick = v[0] == 0.0;
+    }
+    if (!quick) {
+        CHK(rebuild(c, c->b0));
+        c->ri_nbr = c->nbr;
+        c->ri_cnt = c->cnt;
+    }
     const uint32_t n = c->n;
     Rec* r = c->rec[c->b0];
     bool stalled = false;
@@ -2303,7 +2382,7 @@ int sph_reinit_info(sph_ctx* c, uint64_t* out4) {
     out4[0] = c->reinit_walked;
     out4[1] = c->reinit_launches;
     out4[2] = c->reinit_rounds;
-    out4[3] = c->ri_take_turns ? 1u : 0u;
+    out4[3] = (c->ri_take_turns ? 1u : 0u) | (c->ri_nbr != nullptr && c->ri_nbr == c->nbr_in ? 2u : 0u);
     return SPH_OK;
 }
 
@@ -2318,16 +2397,37 @@ int sph_neighbours(sph_ctx* c, int32_t which, uint64_t* row_offsets, uint32_t* c
         src = (c->b0 + 1) % NREC;
         CHK(pack_n_into(c, c->rec[src]));
     }
-    CHK(rebuild(c, src));
-    if (which == SPH_STATE_N) c->list_valid = false;
+    /* SPH_NEIGHBOURS_LISTS=standing (tests): state n+1's sets from lists made on the stepping path's
+     * standing order, the way DensityReinit makes its own, when that can be had */
+    const uint32_t* rows = nullptr;
+    const uint32_t* rcnt = nullptr;
+    if (which == SPH_STATE_NP1 && c->probe_standing) {
+        bool standing = false;
+        CHK(reinit_lists_on_standing_order(c, &standing));
+        if (c->dist) {
+            double v[1] = {standing ? 0.0 : 1.0};
+            CHK(allreduce_host(c, v, 1, 0));
+            standing = v[0] == 0.0;
+        }
+        if (standing) {
+            rows = c->nbr_in;
+            rcnt = c->cnt_in;
+        }
+    }
+    if (!rows) {
+        CHK(rebuild(c, src));
+        if (which == SPH_STATE_N) c->list_valid = false;
+        rows = c->nbr;
+        rcnt = c->cnt;
+    }
     const uint32_t n = c->n;
     uint32_t* counts = (uint32_t*)c->tmp;
     if (c->dim == 3)
-        hipLaunchKernelGGL(k_nbr_count<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], c->nbr, c->cap_k,
-                           c->cnt, c->id, counts);
+        hipLaunchKernelGGL(k_nbr_count<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], rows, c->cap_k,
+                           rcnt, c->id, counts);
     else
-        hipLaunchKernelGGL(k_nbr_count<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], c->nbr, c->cap_k,
-                           c->cnt, c->id, counts);
+        hipLaunchKernelGGL(k_nbr_count<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], rows, c->cap_k,
+                           rcnt, c->id, counts);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> hc(n);
     HIPCHK(hipMemcpyAsync(hc.data(), counts, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
@@ -2352,11 +2452,11 @@ int sph_neighbours(sph_ctx* c, int32_t which, uint64_t* row_offsets, uint32_t* c
         if (hipMemcpyAsync(doffs, row_offsets, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream) !=
             hipSuccess) { rc = SPH_EDEVICE; break; }
         if (c->dim == 3)
-            hipLaunchKernelGGL(k_nbr_fill<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], c->nbr,
-                               c->cap_k, c->cnt, c->id, colid, doffs, dcols);
+            hipLaunchKernelGGL(k_nbr_fill<3>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], rows,
+                               c->cap_k, rcnt, c->id, colid, doffs, dcols);
         else
-            hipLaunchKernelGGL(k_nbr_fill<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], c->nbr,
-                               c->cap_k, c->cnt, c->id, colid, doffs, dcols);
+            hipLaunchKernelGGL(k_nbr_fill<2>, dim3(nblk(n)), dim3(SPH_BLOCK), 0, c->stream, c->dp, c->rec[src], rows,
+                               c->cap_k, rcnt, c->id, colid, doffs, dcols);
         if (hipGetLastError() != hipSuccess) { rc = SPH_EDEVICE; break; }
         if (hipMemcpyAsync(cols, dcols, sizeof(uint32_t) * off, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
             rc = SPH_EDEVICE;

@@ -682,7 +682,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list_ring(const Rec* __rest
                                                           int prune_walls, const uint32_t* __restrict__ hstart,
                                                           uint32_t rin2q, uint32_t* __restrict__ nbr_in,
                                                           uint32_t* __restrict__ cnt_in, const uint32_t* __restrict__ todo,
-                                                          uint32_t todo_n) {
+                                                          uint32_t todo_n, int stale_cells) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[(SPH_BLOCK / 4) * BUILD_STAGE_STRIDE];
     const uint32_t q = threadIdx.x & 3u;
     /* todo != nullptr: the rows of the todo_n particles named there (those k_build_list handed on);
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list_ring(const Rec* __rest
             const int room = (int)e - (int)jl;
             uint32_t ok = room >= 4 ? 0xFu : (room > 0 ? (1u << room) - 1u : 0u);
             if (jl < b) ok &= ~1u;
-            if (self_col) {
+            if (self_col || stale_cells) { /* stale_cells: the particle may have left the column it is filed under */
                 const uint32_t s = i - jl;
                 if (s < 4u) ok &= ~(1u << s);
             }
@@ -853,7 +853,10 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list_ring(const Rec* __rest
  * KEPT candidate -- into 16-byte stores.  Rows, counts and padding are exactly the ring kernel's.
  *   A quad has room for `trips_max` records (at most BUILD_TRIPS).  A particle that needs more (far
  * denser surroundings than the cells were sized for) is named in `todo` instead, counted in need[1],
- * and the host has k_build_list_ring write its rows. */
+ * and the host has k_build_list_ring write its rows.
+ *   stale_cells: the cell table is that of an earlier sort and the particles have moved since (the
+ * caller's range allows for it); a particle is then looked for in every column, not only in the one
+ * it is in now, when it comes to leaving itself out of its row. */
 #define BUILD_TRIPS 40
 #define BUILD_REC_STRIDE (BUILD_TRIPS + 1)
 template <int DIM>
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
                                                           int prune_walls, const uint32_t* __restrict__ hstart,
                                                           uint32_t rin2q, uint32_t* __restrict__ nbr_in,
                                                           uint32_t* __restrict__ cnt_in, uint32_t trips_max,
-                                                          uint32_t* __restrict__ todo) {
+                                                          uint32_t* __restrict__ todo, int stale_cells) {
     __shared__ uint2 s_rec[(SPH_BLOCK / 4) * BUILD_REC_STRIDE];   /* first of the sixteen; masks: list | step list << 16 */
     __shared__ uint32_t s_kb[(SPH_BLOCK / 4) * BUILD_REC_STRIDE]; /* keepers before the record, likewise packed */
     const uint32_t q = threadIdx.x & 3u;
@@ -911,7 +914,7 @@ __global__ __launch_bounds__(SPH_BLOCK) void k_build_list(const Rec* __restrict_
             const int room = (int)e - (int)jl;
             uint32_t ok = room >= 4 ? 0xFu : (room > 0 ? (1u << room) - 1u : 0u);
             if (jl < b) ok &= ~1u;
-            if (self_col) {
+            if (self_col || stale_cells) { /* stale_cells: the particle may have left the column it is filed under */
                 const uint32_t s = i - jl;
                 if (s < 4u) ok &= ~(1u << s);
             }

@@ -93,7 +93,8 @@ def main():
             done += k
             sim.density_reinit()
         info = sim.reinit_info()
-        res["reinit_info"] = np.array([info["walk"], info["launches"], info["rounds"], int(info["took_turns"])])
+        res["reinit_info"] = np.array([info["walk"], info["launches"], info["rounds"], int(info["took_turns"]),
+                                       int(info["standing_lists"])])
     else:
         syncs0 = sim.scalars()["host_syncs"]
         sc = sim.step(args.steps)

@@ -436,6 +436,70 @@ def test_list_build_from_records_and_by_the_ring_kernel_give_the_same_rows(name,
             assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(want[0][k]).view(np.uint8)), (trips, k)
 
 
+@pytest.mark.parametrize("name", ["wcxsph_default", "wcxsph3d_block", "droplet3d"])
+def test_neighbour_sets_from_lists_on_the_standing_order(name, monkeypatch):
+    # The lists DensityReinit makes without a rebuild: the cell table is that of the stepping path's
+    # last sort, the particles have moved on since (some into other columns of cells, where a
+    # particle must still be kept out of its own row).  SPH_NEIGHBOURS_LISTS=standing lets
+    # sph_neighbours read lists made that way: the sets must be the oracle's, frame after frame.
+    monkeypatch.setenv("SPH_NEIGHBOURS_LISTS", "standing")
+    spec = util.drop_cases()[name] if name in util.drop_cases() else util.small_cases()[name]
+    orc, sim = start(spec)
+    rebuilds = sim.scalars()["list_rebuilds"]
+    probed_standing = 0
+    for frame in range(15):
+        orc.step(10)
+        sc = sim.step(10)
+        go, gc = sim.neighbours(capi.STATE_NP1)
+        # the probe made no rebuild of its own when the stepping path's lists stood
+        probed_standing += sim.scalars()["list_rebuilds"] == sc["list_rebuilds"]
+        oo, occ = orc.neighbours(O.STATE_NP1)
+        assert np.array_equal(go, oo) and np.array_equal(gc, occ), "frame %d" % frame
+    assert probed_standing >= 12
+    assert sim.scalars()["list_rebuilds"] - rebuilds >= 3  # the cells did go stale and were renewed along the way
+    sim.close()
+
+
+@pytest.mark.parametrize("name,frames,steps", [("wcxsph3d_block", 4, 7), ("wcxsph_fine", 4, 7), ("wcsph_fine", 4, 7),
+                                               ("droplet3d", 6, 7), ("wcxsph_default", 14, 10)])
+def test_density_reinit_on_the_standing_order_and_after_a_rebuild(name, frames, steps, monkeypatch):
+    # After steps DensityReinit makes its lists on the order and cell table of the stepping path's
+    # last rebuild (the particles have moved since; the build looks that much further); otherwise,
+    # or with SPH_REINIT_LISTS=fresh, it rebuilds.  Same neighbour sets, so the same rho up to the
+    # order of the sums: within one float ulp of each other and of the oracle, frame after frame.
+    spec = util.drop_cases()[name] if name in util.drop_cases() else util.small_cases()[name]
+    oc, _ = util.both_cases(spec)
+    orc = O.Oracle(oc)
+    orc.forces(O.STATE_N)
+    orc.zero_boundary_f(O.STATE_N)
+    sims = {}
+    for how in ("standing", "fresh"):
+        monkeypatch.setenv("SPH_REINIT_LISTS", how)
+        _, pc = util.both_cases(spec)
+        sims[how] = capi.Sim.from_case(pc)
+        sims[how].forces(capi.STATE_N)
+        sims[how].zero_boundary_forces(capi.STATE_N)
+    for frame in range(frames):
+        orc.step(steps)
+        orc.density_reinit()
+        want = orc.get_state(O.STATE_NP1)["rho"]
+        rho = {}
+        for how, sim in sims.items():
+            sc = sim.step(steps)
+            sim.density_reinit()
+            assert sim.reinit_info()["standing_lists"] == (how == "standing")
+            rho[how] = sim.download(capi.STATE_NP1, names=("rho",))["rho"]
+            assert util.float_ulp_diff(rho[how], want).max() <= 1, (how, frame)
+        assert util.float_ulp_diff(rho["standing"], rho["fresh"]).max() <= 1
+    # a call that follows an upload finds no standing lists and rebuilds
+    sim = sims["standing"]
+    sim.upload(capi.STATE_NP1, dict(rho=rho["standing"]))
+    sim.density_reinit()
+    assert not sim.reinit_info()["standing_lists"]
+    for sim in sims.values():
+        sim.close()
+
+
 def test_density_reinit_in_one_launch_and_by_levels_give_the_same_bits(monkeypatch, capfd):
     # a single rank's large case is walked in one launch (every particle as soon as the neighbours
     # before it are done); slab runs walk level by level.  Same sums in the same order: same bits.

@@ -302,7 +302,8 @@ def test_device_buffer_transport(name, nranks, vx, tmp_path):
 
 def reinit_walk_ran(res, walk, monkeypatch=None):
     from sph_amd import capi
-    kind, launches, rounds, turns = (int(v) for v in res["reinit_info"])
+    kind, launches, rounds, turns, standing = (int(v) for v in res["reinit_info"])
+    assert standing == 1  # the call followed steps: its lists were made on the stepping path's order
     print("DensityReinit: walk %d, %d launches, %d rounds%s" % (kind, launches, rounds, ", ranks in turn" if turns else ""))
     if walk == "levels":
         assert kind == capi.REINIT_LEVELS and launches >= 16 * rounds
