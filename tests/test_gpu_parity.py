@@ -185,10 +185,13 @@ def test_trajectory_drift_over_200_steps(name):
         sim.step(10)
         orc.density_reinit()
         sim.density_reinit()
+        # rho straight after every re-initialisation: a neighbour missed or met twice shows here
+        # hundreds of steps before it shows in x
+        u = int(util.float_ulp_diff(sim.download(capi.STATE_NP1, names=("rho",))["rho"], orc.get_state(O.STATE_NP1)["rho"]).max())
+        assert u <= 1, "frame %d: rho %d float ulp from the oracle's" % (frame, u)
         if frame in (0, 4, 9, 19):
             g, o = sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1)
-            report.append((10 * (frame + 1), util.rel_err(g["x"].T, o["x"]), util.rel_err(g["v"].T, o["v"]),
-                           int(util.float_ulp_diff(g["rho"], o["rho"]).max())))
+            report.append((10 * (frame + 1), util.rel_err(g["x"].T, o["x"]), util.rel_err(g["v"].T, o["v"]), u))
     print("\n%s: steps, rel err x, rel err v, rho ulp: %s" % (name, report))
     g, o = sim.download(capi.STATE_NP1), orc.get_state(O.STATE_NP1)
     assert util.rel_err(g["x"].T, o["x"]) <= TOL and util.rel_err(g["v"].T, o["v"]) <= TOL
