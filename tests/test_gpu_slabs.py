@@ -369,6 +369,26 @@ def test_density_reinit_across_slabs_with_particles_changing_owner(walk, transpo
         assert util.rel_err(res["step_" + k].T, o[k]) <= TOL, k
 
 
+def test_density_reinit_across_slabs_after_many_steps(tmp_path):
+    # frames of ten steps: by the later calls the particles have left the columns of cells they
+    # were sorted into, and the call makes its lists on that standing order (slab runs: the
+    # neighbours' particles too)
+    spec = util.drop_cases()["droplet3d"]
+    res = run_slabs(spec, 2, tmp_path, steps=40, reinit=10, skin=0.25)
+    assert int(res["reinit_info"][4]) == 1
+    oc, _ = util.both_cases(spec)
+    orc = O.Oracle(oc)
+    orc.forces(O.STATE_N)
+    orc.zero_boundary_f(O.STATE_N)
+    for frame in range(4):
+        orc.step(10)
+        orc.density_reinit()
+    assert util.float_ulp_diff(res["step_np1_rho"], orc.get_state(O.STATE_NP1)["rho"]).max() <= 1
+    o = orc.get_state(O.STATE_N)
+    for k in ("x", "v", "f"):
+        assert util.rel_err(res["step_" + k].T, o[k]) <= TOL, k
+
+
 @pytest.mark.parametrize("walk", ["flow", "flow_together"])
 def test_density_reinit_of_a_medium_size_case_on_two_slabs(walk, tmp_path, monkeypatch):
     # ~0.57 M particles, dependency chains of thousands of particles crossing the plane several
