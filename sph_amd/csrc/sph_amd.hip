@@ -1979,6 +1979,9 @@ int reinit_lists_on_standing_order(sph_ctx* c, bool* done) {
         if (c->trace) fprintf(stderr, "[sph] reinit: no lists on the standing order: range %.4g, cell edge %.4g\n", range, 1.0 / c->grid.inv[0]);
         return SPH_OK;
     }
+    /* the rows go where the step lists live; a context made without step lists has no such rows,
+     * and none are made for this */
+    if (c->inner_mode < 0 && !c->nbr_in) return SPH_OK;
     bool ok = true;
     CHK(ensure_step_lists(c, &ok));
     const Rec* rec = c->rec[c->b0];
