@@ -902,7 +902,10 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
             ++k;
         }
     const int n_nd = k;
-    for (int q = 0; q < 2; ++q)
+    /* f, V, Rrho and p of state n+1 hold nothing of their own after a committed step (see
+     * settle_np1_outputs): they are filled from state n's, in the new order, when asked for */
+    const bool outputs_live = !c->np1_out_in_n;
+    for (int q = 0; q < 2 && outputs_live; ++q)
         for (int d = 0; d < dim; ++d) {
             if (q == 1 && !c->xsph) continue;
             a.sd[k] = c->pd[q * 3 + d];
@@ -915,11 +918,14 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
         a.sf[q] = c->nfl[q];
         a.df[q] = c->nfl_alt[q];
     }
-    a.sf[4] = c->pRrho;
-    a.df[4] = c->pRrho_alt;
-    a.sf[5] = c->pp;
-    a.df[5] = c->pp_alt;
-    a.nf = 6;
+    a.nf = 4;
+    if (outputs_live) {
+        a.sf[4] = c->pRrho;
+        a.df[4] = c->pRrho_alt;
+        a.sf[5] = c->pp;
+        a.df[5] = c->pp_alt;
+        a.nf = 6;
+    }
     a.rs[0] = c->rec[c->b0];
     a.rd[0] = c->rec_alt;
     a.nr = 1;
@@ -944,8 +950,10 @@ int rebuild(sph_ctx* c, int src, bool for_step = false, bool may_migrate = false
     for (int q = 0; q < n_nd; ++q) std::swap(c->nd[map_nd[q]], c->nd_alt[map_nd[q]]);
     for (int q = n_nd; q < k; ++q) std::swap(c->pd[map_pd[q - n_nd]], c->pd_alt[map_pd[q - n_nd]]);
     for (int q = 0; q < 4; ++q) std::swap(c->nfl[q], c->nfl_alt[q]);
-    std::swap(c->pRrho, c->pRrho_alt);
-    std::swap(c->pp, c->pp_alt);
+    if (outputs_live) {
+        std::swap(c->pRrho, c->pRrho_alt);
+        std::swap(c->pp, c->pp_alt);
+    }
     std::swap(c->rec[c->b0], c->rec_alt);
     std::swap(c->id, c->id_alt);
     if (c->dist) std::swap(c->gid, c->gid_alt);
